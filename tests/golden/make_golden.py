@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the reference checkout (run in the build container only).
+
+    python tests/golden/make_golden.py [/root/reference]
+
+Copies the reference's own test fixtures (DATA: input JPEGs / raw RGB dumps and the
+committed expected outputs, never source code) and records SHA-256 digests of the
+reference's committed golden outputs:
+
+  decode pins  tests/regression/gold/*.jpg.{ycc,rgb}      (tests/regression/tests.swift:129)
+               examples/decode-advanced/karlie-2019.jpg-*.gray + .rgb   (per-stage IDCT pin)
+               examples/decode-basic/karlie-kwk-2019.jpg.rgb
+  encode pins  quantised coefficients inside examples/encode-basic/*.jpg, produced by the
+               reference from karlie-milan-sp12-2011.rgb (examples/encode-basic/main.swift)
+
+The 13 MB of raw gold dumps are hashed, not copied (color-sequential-1 and the three
+decode-advanced planes are kept in full so a failing test can localise a mismatch).
+Image licences travel with the files: see ATTRIBUTION.md.
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import jpeg_reader as R  # noqa: E402
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+
+
+def sha(b) -> str:
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def sha_file(p) -> str:
+    return sha(open(p, "rb").read())
+
+
+def copy(src, dst):
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    shutil.copyfile(src, dst)
+    os.chmod(dst, 0o644)
+
+
+def describe(img):
+    return {
+        "width": img.width, "height": img.height, "precision": img.precision,
+        "process": img.process, "scans": img.scans,
+        "restart_interval": img.restart_interval,
+        "component_ids": [c.ident for c in img.components],
+        "factors": [list(f) for f in img.factors],
+        "units": [[c.ux, c.uy] for c in img.components],
+        "coef_sha256": [sha(np.ascontiguousarray(p).tobytes()) for p in img.planes],
+        "quanta_zigzag": [q.tolist() for q in img.quanta],
+    }
+
+
+def main():
+    manifest = {"reference": "tayloraswift/jpeg @ 2024_08_07", "decode": [], "encode": {}}
+
+    # ---- decode: regression golds (12) + restart fixtures (4, no gold) ----------------
+    ddir = os.path.join(REF, "tests/integration/decode")
+    gdir = os.path.join(REF, "tests/regression/gold")
+    names = sorted(f for f in os.listdir(ddir) if f.endswith(".jpg"))
+    for name in names:
+        src = os.path.join(ddir, name)
+        copy(src, os.path.join(HERE, "decode", name))
+        img = R.read_jpeg(src)
+        e = {"name": name, "file": "decode/" + name, "file_sha256": sha_file(src),
+             "origin": "tests/integration/decode/" + name}
+        e.update(describe(img))
+        gold = {}
+        for ext in ("ycc", "rgb"):
+            g = os.path.join(gdir, name + "." + ext)
+            if os.path.exists(g):
+                gold[ext + "_sha256"] = sha_file(g)
+                gold[ext + "_nbytes"] = os.path.getsize(g)
+                if name == "color-sequential-1.jpg":
+                    copy(g, os.path.join(HERE, "decode", name + "." + ext))
+                    gold[ext + "_file"] = "decode/" + name + "." + ext
+        if gold:
+            gold["origin"] = "tests/regression/gold/" + name + ".{ycc,rgb}"
+        e["gold"] = gold
+        manifest["decode"].append(e)
+
+    # ---- decode: examples/decode-advanced (per-plane IDCT pin) -------------------------
+    adv = os.path.join(REF, "examples/decode-advanced")
+    name = "karlie-2019.jpg"
+    copy(os.path.join(adv, name), os.path.join(HERE, "decode", name))
+    img = R.read_jpeg(os.path.join(adv, name))
+    e = {"name": name, "file": "decode/" + name, "file_sha256": sha_file(os.path.join(adv, name)),
+         "origin": "examples/decode-advanced/" + name}
+    e.update(describe(img))
+    gold = {"rgb_sha256": sha_file(os.path.join(adv, name + ".rgb")),
+            "rgb_nbytes": os.path.getsize(os.path.join(adv, name + ".rgb")),
+            "origin": "examples/decode-advanced/karlie-2019.jpg{.rgb,-N.WxH.gray}",
+            "planes": []}
+    for p, dims in enumerate(["640x432", "320x216", "320x216"]):
+        g = os.path.join(adv, f"{name}-{p}.{dims}.gray")
+        copy(g, os.path.join(HERE, "decode", os.path.basename(g)))
+        gold["planes"].append({"file": "decode/" + os.path.basename(g),
+                               "sha256": sha_file(g), "dims": dims})
+    e["gold"] = gold
+    manifest["decode"].append(e)
+
+    # ---- decode: examples/decode-basic -------------------------------------------------
+    bas = os.path.join(REF, "examples/decode-basic")
+    name = "karlie-kwk-2019.jpg"
+    copy(os.path.join(bas, name), os.path.join(HERE, "decode", name))
+    img = R.read_jpeg(os.path.join(bas, name))
+    e = {"name": name, "file": "decode/" + name, "file_sha256": sha_file(os.path.join(bas, name)),
+         "origin": "examples/decode-basic/" + name}
+    e.update(describe(img))
+    e["gold"] = {"rgb_sha256": sha_file(os.path.join(bas, name + ".rgb")),
+                 "rgb_nbytes": os.path.getsize(os.path.join(bas, name + ".rgb")),
+                 "origin": "examples/decode-basic/karlie-kwk-2019.jpg.rgb"}
+    manifest["decode"].append(e)
+
+    # ---- encode: examples/encode-basic ---------------------------------------------------
+    enc = os.path.join(REF, "examples/encode-basic")
+    stem = "karlie-milan-sp12-2011"
+    copy(os.path.join(enc, stem + ".rgb"), os.path.join(HERE, "encode", stem + ".rgb"))
+    cases = []
+    keep = {1.0, 8.0}
+    for mode, lf in [("4-4-4", (1, 1)), ("4-4-0", (1, 2)), ("4-2-2", (2, 1)), ("4-2-0", (2, 2))]:
+        for level in [0.0, 0.125, 0.25, 0.5, 1.0, 2.0, 4.0, 8.0]:
+            fn = f"{stem}-{mode}-{level}.jpg"
+            img = R.read_jpeg(os.path.join(enc, fn))
+            c = {"mode": mode, "level": level, "origin": "examples/encode-basic/" + fn,
+                 "factors": [list(lf), [1, 1], [1, 1]],
+                 "units": [[c.ux, c.uy] for c in img.components],
+                 "quanta_zigzag": [q.tolist() for q in img.quanta],
+                 "coef_sha256": [sha(np.ascontiguousarray(p).tobytes()) for p in img.planes]}
+            if level in keep:
+                copy(os.path.join(enc, fn), os.path.join(HERE, "encode", fn))
+                c["file"] = "encode/" + fn
+            cases.append(c)
+    manifest["encode"] = {
+        "source": "encode/" + stem + ".rgb", "source_sha256": sha_file(os.path.join(enc, stem + ".rgb")),
+        "origin": "examples/encode-basic/" + stem + ".rgb", "size": [400, 665], "cases": cases}
+
+    # ---- attribution ----------------------------------------------------------------------
+    with open(os.path.join(HERE, "ATTRIBUTION.md"), "w") as f:
+        f.write("# Image fixtures: attribution\n\n"
+                "The image files under `decode/` and `encode/` are unmodified copies of test and\n"
+                "example fixtures of tayloraswift/jpeg (reference @ 2024_08_07), used here as\n"
+                "known-answer test data only.  Credits as given by the reference:\n\n"
+                "## tests/integration/decode/attribution.md\n\n")
+        f.write(open(os.path.join(ddir, "attribution.md")).read())
+        f.write("\n## examples/attribution.md\n\n")
+        f.write(open(os.path.join(REF, "examples/attribution.md")).read())
+
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    print("wrote", os.path.join(HERE, "MANIFEST.json"))
+
+
+if __name__ == "__main__":
+    main()

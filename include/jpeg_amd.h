@@ -1,0 +1,199 @@
+/* jpeg_amd.h -- C ABI of the MI355X (gfx950) spectral pipeline.
+ *
+ * Drop-in boundary for the one data-parallel hot path of tayloraswift/jpeg
+ * (reference @ 2024_08_07; citations below are sources/jpeg/<file>:<lines>):
+ *
+ *   decode   Spectral.idct()              decode.swift:4154-4165  (per plane :4101-4133)
+ *            Planar.interleaved(cosite:)  decode.swift:4182-4276
+ *            Rectangular.unpack(as:)      decode.swift:4291-4298  (jpeg.swift:441-453, 493-572)
+ *   encode   Rectangular.pack(...)        encode.swift:453-464    (jpeg.swift:463-478, 527-599)
+ *            Rectangular.decomposed()     encode.swift:389-425
+ *            Planar.fdct(quanta:)         encode.swift:353-370    (per plane :199-248)
+ *
+ * The reference has no FFI for this path (it is pure Swift); these entry points are
+ * what a Swift shim binds with @_silgen_name / a module map.
+ * Results are bit-identical to the reference: the float32 operation order of the
+ * reference is reproduced exactly (kernels are built with -ffp-contract=off).
+ *
+ * Conventions
+ *   - plain C, no exceptions, no aborts: every call returns 0 (JPEG_AMD_OK) or a
+ *     negative jpeg_amd_status; contract violations the reference traps on
+ *     (precondition failures) come back as JPEG_AMD_EINVAL.
+ *   - `d_` parameters are DEVICE pointers (HBM); `h_` parameters are HOST pointers.
+ *     Quantisation tables are tiny and are HOST pointers unless named `d_`.
+ *   - a ctx owns one HIP stream (or borrows the caller's), scratch memory and
+ *     timing events.  A ctx is single-threaded; different ctxs may run concurrently.
+ *     All device entry points are asynchronous on the ctx stream.
+ *   - coefficient planes: int16 [units_y][units_x][64], ZIGZAG order inside a block
+ *     (decode.swift:1434, 1466).  Spatial planes: uint16 [8*units_y][8*units_x]
+ *     (decode.swift:1548-1598).  Rectangular: uint16 [H][W][nplanes]
+ *     (decode.swift:1650-1718).  Colours: uint8 [H*W][3] (jpeg.swift:160-269).
+ */
+#ifndef JPEG_AMD_H
+#define JPEG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPEG_AMD_VERSION 100  /* 0.1.0 */
+#define JPEG_AMD_MAX_PLANES 4
+
+typedef enum jpeg_amd_status {
+    JPEG_AMD_OK      = 0,
+    JPEG_AMD_EINVAL  = -1, /* bad argument / violated precondition of the reference */
+    JPEG_AMD_ENOMEM  = -2, /* device or host allocation failed */
+    JPEG_AMD_EHIP    = -3, /* HIP runtime error; see jpeg_amd_last_hip_error */
+    JPEG_AMD_ENODEV  = -4, /* no such device / no gfx950 code object for it */
+    JPEG_AMD_ENOSUP  = -5  /* valid in the reference but not implemented here */
+} jpeg_amd_status;
+
+typedef struct jpeg_amd_ctx jpeg_amd_ctx;
+
+/* Image geometry = the part of JPEG.Layout<Format> + Spectral/Planar sizes the
+ * hot path reads (jpeg.swift:1084-1635, decode.swift:2181-2190, 2456-2495).
+ * Only RECOGNISED planes are listed; scale is the max sampling factor over ALL
+ * components of the frame (it can exceed every listed factor). */
+typedef struct jpeg_amd_layout {
+    int32_t width, height;                   /* image size in pixels, > 0 */
+    int32_t precision;                       /* Format.precision, 1..16 */
+    int32_t nplanes;                         /* 1..JPEG_AMD_MAX_PLANES */
+    int32_t scale_x, scale_y;                /* Layout.scale */
+    int32_t factor_x[JPEG_AMD_MAX_PLANES];   /* Component.factor */
+    int32_t factor_y[JPEG_AMD_MAX_PLANES];
+    int32_t units_x[JPEG_AMD_MAX_PLANES];    /* Plane.units (data units per row / column) */
+    int32_t units_y[JPEG_AMD_MAX_PLANES];
+    int32_t qi[JPEG_AMD_MAX_PLANES];         /* Plane.q: index into the quanta array */
+} jpeg_amd_layout;
+
+/* colour targets of Rectangular.unpack / pack (the built-in JPEG.Color types) */
+typedef enum jpeg_amd_color {
+    JPEG_AMD_COLOR_YCC8 = 0,  /* JPEG.YCbCr  jpeg.swift:493-539 */
+    JPEG_AMD_COLOR_RGB8 = 1   /* JPEG.RGB    jpeg.swift:551-599 */
+} jpeg_amd_color;
+
+/* ---- library / context --------------------------------------------------------- */
+int         jpeg_amd_version(void);
+const char *jpeg_amd_strerror(int status);
+int         jpeg_amd_device_count(int *count);
+/* stream: the hipStream_t to launch on (borrowed, e.g. torch's current stream; NULL is
+ * the device's default stream).  With JPEG_AMD_CTX_OWN_STREAM in flags, `stream` is
+ * ignored and the ctx creates (and later destroys) a private non-blocking stream. */
+#define JPEG_AMD_CTX_OWN_STREAM 1
+int         jpeg_amd_ctx_create(int device, void *stream, int flags, jpeg_amd_ctx **ctx);
+int         jpeg_amd_ctx_destroy(jpeg_amd_ctx *ctx);
+int         jpeg_amd_ctx_synchronize(jpeg_amd_ctx *ctx);
+int         jpeg_amd_last_hip_error(const jpeg_amd_ctx *ctx); /* raw hipError_t */
+/* fill in units_x/units_y = ceil(size * factor / (8 * scale))  decode.swift:2606-2616 */
+int         jpeg_amd_layout_units(jpeg_amd_layout *layout);
+
+/* ---- device memory + timing (so a non-HIP host language can keep data resident) -- */
+int jpeg_amd_malloc(jpeg_amd_ctx *ctx, size_t bytes, void **d_ptr);
+int jpeg_amd_free(jpeg_amd_ctx *ctx, void *d_ptr);
+int jpeg_amd_memcpy_h2d(jpeg_amd_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int jpeg_amd_memcpy_d2h(jpeg_amd_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* HIP events on the ctx stream; end() synchronises and returns elapsed ms */
+int jpeg_amd_timer_begin(jpeg_amd_ctx *ctx);
+int jpeg_amd_timer_end(jpeg_amd_ctx *ctx, float *elapsed_ms);
+
+/* ---- decode stages (device-resident) ---------------------------------------------- */
+
+/* Spectral.Plane.idct(quanta:precision:)  decode.swift:4101-4133 (+ modulate :3984-4017,
+ * load :4020-4039, idct8 :4042-4093, idct8x8 :4095-4099).  One plane. */
+int jpeg_amd_idct_plane(jpeg_amd_ctx *ctx, const int16_t *d_coef, int units_x, int units_y,
+                        const uint16_t h_quanta_zigzag[64], int precision,
+                        uint16_t *d_plane);
+
+/* Spectral.idct()  decode.swift:4154-4165: every plane of an image.
+ * h_quanta: [ntables][64] zigzag; plane p uses table layout->qi[p]. */
+int jpeg_amd_spectral_idct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                           const int16_t *const d_coef[], const uint16_t *h_quanta,
+                           int ntables, uint16_t *const d_planes[]);
+
+/* Planar.interleaved(cosite:)  decode.swift:4182-4276 */
+int jpeg_amd_planar_interleaved(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                                const uint16_t *const d_planes[], int cosited,
+                                uint16_t *d_rect);
+
+/* Rectangular.unpack(as:) for the built-in 8-bit colour targets  decode.swift:4291-4298.
+ * nplanes = 1 (y8 / nonconforming1x8) or 3 (ycc8 / nonconforming3x8). */
+int jpeg_amd_rectangular_unpack(jpeg_amd_ctx *ctx, const uint16_t *d_rect, size_t npixels,
+                                int nplanes, jpeg_amd_color color, uint8_t *d_pixels);
+
+/* Fused Spectral -> pixels: == idct().interleaved(cosite:).unpack(as:) bit for bit,
+ * without materialising Planar / Rectangular in HBM (8-bit formats, 1 or 3 planes).
+ * n_images images of identical layout; image i reads d_coef[p] + i*coef_stride[p]
+ * (int16 elements), table set i*quanta_stride (uint16 elements) of d_quanta and writes
+ * d_pixels + i*pixel_stride (bytes).  d_quanta: DEVICE pointer [..][ntables][64]. */
+int jpeg_amd_decode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout, int n_images,
+                          const int16_t *const d_coef[], const size_t coef_stride[],
+                          const uint16_t *d_quanta, size_t quanta_stride, int ntables,
+                          int cosited, jpeg_amd_color color,
+                          uint8_t *d_pixels, size_t pixel_stride);
+/* single image, host tables */
+int jpeg_amd_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                    const int16_t *const d_coef[], const uint16_t *h_quanta, int ntables,
+                    int cosited, jpeg_amd_color color, uint8_t *d_pixels);
+
+/* ---- encode stages (device-resident) ---------------------------------------------- */
+
+/* Rectangular.pack(size:layout:metadata:pixels:)  encode.swift:453-464 */
+int jpeg_amd_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *d_pixels, size_t npixels,
+                              int nplanes, jpeg_amd_color color, uint16_t *d_rect);
+
+/* Rectangular.decomposed()  encode.swift:389-425 */
+int jpeg_amd_rectangular_decomposed(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                                    const uint16_t *d_rect, uint16_t *const d_planes[]);
+
+/* Spectral.Plane.fdct(_:quanta:precision:)  encode.swift:199-248 */
+int jpeg_amd_fdct_plane(jpeg_amd_ctx *ctx, const uint16_t *d_plane, int units_x, int units_y,
+                        const uint16_t h_quanta_zigzag[64], int precision, int16_t *d_coef);
+
+/* Planar.fdct(quanta:)  encode.swift:353-370 */
+int jpeg_amd_planar_fdct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                         const uint16_t *const d_planes[], const uint16_t *h_quanta,
+                         int ntables, int16_t *const d_coef[]);
+
+/* Fused pixels -> Spectral: == pack(...).decomposed().fdct(quanta:) bit for bit
+ * (8-bit formats, 1 or 3 planes).  Strides as in jpeg_amd_decode_batch. */
+int jpeg_amd_encode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout, int n_images,
+                          const uint8_t *d_pixels, size_t pixel_stride, jpeg_amd_color color,
+                          const uint16_t *d_quanta, size_t quanta_stride, int ntables,
+                          int16_t *const d_coef[], const size_t coef_stride[]);
+int jpeg_amd_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                    const uint8_t *d_pixels, jpeg_amd_color color,
+                    const uint16_t *h_quanta, int ntables, int16_t *const d_coef[]);
+
+/* ---- host-buffer conveniences: what the Swift shim calls ---------------------------
+ * Same semantics as the calls above with every buffer in HOST memory: the library
+ * uploads inputs, runs the kernels and downloads outputs (synchronous). */
+int jpeg_amd_host_spectral_idct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                                const int16_t *const h_coef[], const uint16_t *h_quanta,
+                                int ntables, uint16_t *const h_planes[]);
+int jpeg_amd_host_planar_interleaved(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                                     const uint16_t *const h_planes[], int cosited,
+                                     uint16_t *h_rect);
+int jpeg_amd_host_rectangular_unpack(jpeg_amd_ctx *ctx, const uint16_t *h_rect,
+                                     size_t npixels, int nplanes, jpeg_amd_color color,
+                                     uint8_t *h_pixels);
+int jpeg_amd_host_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                         const int16_t *const h_coef[], const uint16_t *h_quanta, int ntables,
+                         int cosited, jpeg_amd_color color, uint8_t *h_pixels);
+int jpeg_amd_host_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *h_pixels, size_t npixels,
+                                   int nplanes, jpeg_amd_color color, uint16_t *h_rect);
+int jpeg_amd_host_rectangular_decomposed(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                                         const uint16_t *h_rect, uint16_t *const h_planes[]);
+int jpeg_amd_host_planar_fdct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                              const uint16_t *const h_planes[], const uint16_t *h_quanta,
+                              int ntables, int16_t *const h_coef[]);
+int jpeg_amd_host_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                         const uint8_t *h_pixels, jpeg_amd_color color,
+                         const uint16_t *h_quanta, int ntables, int16_t *const h_coef[]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEG_AMD_H */

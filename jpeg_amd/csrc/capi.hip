@@ -1,0 +1,707 @@
+// capi.hip -- the C ABI declared in include/jpeg_amd.h: argument validation, context /
+// stream / scratch management, table staging and the host-buffer conveniences.
+// No arithmetic on samples happens here; all of it is in kernels_*.hip.
+#pragma clang fp contract(off)
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace jpeg_amd;
+
+struct jpeg_amd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    uint16_t *d_qstage = nullptr;  // ring of staged host tables
+    int qslot = 0;
+    int last_hip = 0;
+};
+
+namespace {
+
+constexpr int kQSlots = 32;                                   // staged table sets in flight
+constexpr size_t kQSlotElems = JPEG_AMD_MAX_PLANES * 64;      // uint16 per slot
+
+#define JA_HIP(ctx, expr)                                         \
+    do {                                                          \
+        const hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) {                                   \
+            (ctx)->last_hip = (int)e_;                            \
+            return e_ == hipErrorOutOfMemory ? JPEG_AMD_ENOMEM : JPEG_AMD_EHIP; \
+        }                                                         \
+    } while (0)
+
+#define JA_TRY(expr)                          \
+    do {                                      \
+        const int s_ = (expr);                \
+        if (s_ != JPEG_AMD_OK) return s_;     \
+    } while (0)
+
+int bind(jpeg_amd_ctx *ctx)
+{
+    if (!ctx) return JPEG_AMD_EINVAL;
+    JA_HIP(ctx, hipSetDevice(ctx->device));
+    return JPEG_AMD_OK;
+}
+
+int units_of(int size, int stride) { return size / stride + (size % stride != 0 ? 1 : 0); }
+
+// The preconditions the reference traps on (decode.swift:1710-1712, 2227, 2599) plus the
+// bounds this ABI needs.
+int check_layout(const jpeg_amd_layout *L, int ntables)
+{
+    if (!L) return JPEG_AMD_EINVAL;
+    if (L->width <= 0 || L->height <= 0) return JPEG_AMD_EINVAL;
+    if (L->precision < 1 || L->precision > 16) return JPEG_AMD_EINVAL;
+    if (L->nplanes < 1 || L->nplanes > JPEG_AMD_MAX_PLANES) return JPEG_AMD_EINVAL;
+    if (L->scale_x < 1 || L->scale_y < 1) return JPEG_AMD_EINVAL;
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (L->factor_x[p] < 1 || L->factor_y[p] < 1) return JPEG_AMD_EINVAL;
+        if (L->factor_x[p] > L->scale_x || L->factor_y[p] > L->scale_y) return JPEG_AMD_EINVAL;
+        if (L->units_x[p] < 0 || L->units_y[p] < 0) return JPEG_AMD_EINVAL;
+        if ((long long)L->units_x[p] * L->units_y[p] > (1LL << 30)) return JPEG_AMD_EINVAL;
+        if (ntables >= 0 && (L->qi[p] < 0 || L->qi[p] >= ntables)) return JPEG_AMD_EINVAL;
+    }
+    return JPEG_AMD_OK;
+}
+
+// Planar.interleaved reads plane samples up to the image size (crop copy) or up to the
+// padded plane (bilinear): the planes must cover the image (decode.swift:4190-4215).
+int check_planes_cover_image(const jpeg_amd_layout *L)
+{
+    for (int p = 0; p < L->nplanes; ++p) {
+        const bool direct = L->nplanes == 1 ||
+                            (L->factor_x[p] == L->scale_x && L->factor_y[p] == L->scale_y);
+        if (direct) {
+            if (8 * L->units_x[p] < L->width || 8 * L->units_y[p] < L->height) return JPEG_AMD_EINVAL;
+        } else if (L->units_x[p] < 1 || L->units_y[p] < 1) {
+            return JPEG_AMD_EINVAL;
+        }
+    }
+    return JPEG_AMD_OK;
+}
+
+size_t plane_samples(const jpeg_amd_layout *L, int p)
+{
+    return (size_t)64 * L->units_x[p] * L->units_y[p];
+}
+
+int ensure_scratch(jpeg_amd_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return JPEG_AMD_OK;
+    if (ctx->scratch) {
+        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        JA_HIP(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 4096;
+    JA_HIP(ctx, hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+    return JPEG_AMD_OK;
+}
+
+// Copy host tables [ntables][64] into the next ring slot; returns the device pointer.
+int stage_quanta(jpeg_amd_ctx *ctx, const uint16_t *h_quanta, int ntables, const uint16_t **d_out)
+{
+    if (!h_quanta || ntables < 1 || ntables > JPEG_AMD_MAX_PLANES) return JPEG_AMD_EINVAL;
+    uint16_t *slot = ctx->d_qstage + (size_t)ctx->qslot * kQSlotElems;
+    ctx->qslot = (ctx->qslot + 1) % kQSlots;
+    JA_HIP(ctx, hipMemcpyAsync(slot, h_quanta, (size_t)ntables * 64 * sizeof(uint16_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+    *d_out = slot;
+    return JPEG_AMD_OK;
+}
+
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+int jpeg_amd_version(void) { return JPEG_AMD_VERSION; }
+
+const char *jpeg_amd_strerror(int status)
+{
+    switch (status) {
+        case JPEG_AMD_OK: return "ok";
+        case JPEG_AMD_EINVAL: return "invalid argument (violated precondition)";
+        case JPEG_AMD_ENOMEM: return "out of memory";
+        case JPEG_AMD_EHIP: return "HIP runtime error";
+        case JPEG_AMD_ENODEV: return "no such device";
+        case JPEG_AMD_ENOSUP: return "not supported";
+        default: return "unknown status";
+    }
+}
+
+int jpeg_amd_device_count(int *count)
+{
+    if (!count) return JPEG_AMD_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return JPEG_AMD_ENODEV; }
+    *count = n;
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_ctx_create(int device, void *stream, int flags, jpeg_amd_ctx **out)
+{
+    if (!out) return JPEG_AMD_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return JPEG_AMD_ENODEV;
+    jpeg_amd_ctx *ctx = new (std::nothrow) jpeg_amd_ctx();
+    if (!ctx) return JPEG_AMD_ENOMEM;
+    ctx->device = device;
+    int status = JPEG_AMD_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { status = JPEG_AMD_ENODEV; break; }
+        if (flags & JPEG_AMD_CTX_OWN_STREAM) {
+            if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { status = JPEG_AMD_EHIP; break; }
+            ctx->own_stream = true;
+        } else {
+            ctx->stream = static_cast<hipStream_t>(stream);  // NULL = the default stream
+        }
+        if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { status = JPEG_AMD_EHIP; break; }
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_qstage), kQSlots * kQSlotElems * sizeof(uint16_t)) != hipSuccess) { status = JPEG_AMD_ENOMEM; break; }
+    } while (0);
+    if (status != JPEG_AMD_OK) {
+        jpeg_amd_ctx_destroy(ctx);
+        return status;
+    }
+    *out = ctx;
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_ctx_destroy(jpeg_amd_ctx *ctx)
+{
+    if (!ctx) return JPEG_AMD_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->d_qstage) (void)hipFree(ctx->d_qstage);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_ctx_synchronize(jpeg_amd_ctx *ctx)
+{
+    JA_TRY(bind(ctx));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_last_hip_error(const jpeg_amd_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+
+int jpeg_amd_layout_units(jpeg_amd_layout *L)
+{
+    if (!L || L->nplanes < 1 || L->nplanes > JPEG_AMD_MAX_PLANES || L->scale_x < 1 ||
+        L->scale_y < 1 || L->width <= 0 || L->height <= 0)
+        return JPEG_AMD_EINVAL;
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (L->factor_x[p] < 1 || L->factor_y[p] < 1) return JPEG_AMD_EINVAL;
+        L->units_x[p] = units_of(L->width * L->factor_x[p], 8 * L->scale_x);
+        L->units_y[p] = units_of(L->height * L->factor_y[p], 8 * L->scale_y);
+    }
+    return JPEG_AMD_OK;
+}
+
+// ---- memory + timing --------------------------------------------------------------------
+
+int jpeg_amd_malloc(jpeg_amd_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    JA_TRY(bind(ctx));
+    if (!d_ptr) return JPEG_AMD_EINVAL;
+    *d_ptr = nullptr;
+    if (bytes == 0) return JPEG_AMD_OK;
+    JA_HIP(ctx, hipMalloc(d_ptr, bytes));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_free(jpeg_amd_ctx *ctx, void *d_ptr)
+{
+    JA_TRY(bind(ctx));
+    if (!d_ptr) return JPEG_AMD_OK;
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    JA_HIP(ctx, hipFree(d_ptr));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_memcpy_h2d(jpeg_amd_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    JA_TRY(bind(ctx));
+    if (bytes == 0) return JPEG_AMD_OK;
+    if (!d_dst || !h_src) return JPEG_AMD_EINVAL;
+    JA_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_memcpy_d2h(jpeg_amd_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    JA_TRY(bind(ctx));
+    if (bytes == 0) return JPEG_AMD_OK;
+    if (!h_dst || !d_src) return JPEG_AMD_EINVAL;
+    JA_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_timer_begin(jpeg_amd_ctx *ctx)
+{
+    JA_TRY(bind(ctx));
+    JA_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_timer_end(jpeg_amd_ctx *ctx, float *elapsed_ms)
+{
+    JA_TRY(bind(ctx));
+    if (!elapsed_ms) return JPEG_AMD_EINVAL;
+    JA_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    JA_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+    JA_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
+    return JPEG_AMD_OK;
+}
+
+// ---- decode stages ----------------------------------------------------------------------
+
+int jpeg_amd_idct_plane(jpeg_amd_ctx *ctx, const int16_t *d_coef, int units_x, int units_y,
+                        const uint16_t h_quanta_zigzag[64], int precision, uint16_t *d_plane)
+{
+    JA_TRY(bind(ctx));
+    if (units_x < 0 || units_y < 0 || precision < 1 || precision > 16) return JPEG_AMD_EINVAL;
+    if ((long long)units_x * units_y > (1LL << 30)) return JPEG_AMD_EINVAL;
+    if (units_x == 0 || units_y == 0) return JPEG_AMD_OK;
+    if (!d_coef || !d_plane) return JPEG_AMD_EINVAL;
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta_zigzag, 1, &d_q));
+    JA_HIP(ctx, launch_idct_plane(ctx->stream, 1, d_coef, 0, QuantaRef{d_q, 0}, 0, units_x,
+                                  units_y, precision, d_plane, 0, false));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_spectral_idct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                           const int16_t *const d_coef[], const uint16_t *h_quanta, int ntables,
+                           uint16_t *const d_planes[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (!d_coef || !d_planes) return JPEG_AMD_EINVAL;
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (plane_samples(L, p) == 0) continue;
+        if (!d_coef[p] || !d_planes[p]) return JPEG_AMD_EINVAL;
+        JA_HIP(ctx, launch_idct_plane(ctx->stream, 1, d_coef[p], 0, QuantaRef{d_q, 0}, L->qi[p],
+                                      L->units_x[p], L->units_y[p], L->precision, d_planes[p],
+                                      0, false));
+    }
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_planar_interleaved(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                                const uint16_t *const d_planes[], int cosited, uint16_t *d_rect)
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, -1));
+    JA_TRY(check_planes_cover_image(L));
+    if (!d_planes || !d_rect) return JPEG_AMD_EINVAL;
+    PlaneSet ps{};
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (!d_planes[p]) return JPEG_AMD_EINVAL;
+        ps.ptr[p] = d_planes[p];
+    }
+    JA_HIP(ctx, launch_planar_to_pixels(ctx->stream, 1, *L, ps, false, cosited != 0,
+                                        PixelKind::Rect16, d_rect, 0));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_rectangular_unpack(jpeg_amd_ctx *ctx, const uint16_t *d_rect, size_t npixels,
+                                int nplanes, jpeg_amd_color color, uint8_t *d_pixels)
+{
+    JA_TRY(bind(ctx));
+    if (nplanes != 1 && nplanes != 3) return JPEG_AMD_EINVAL;
+    if (color != JPEG_AMD_COLOR_YCC8 && color != JPEG_AMD_COLOR_RGB8) return JPEG_AMD_EINVAL;
+    if (npixels == 0) return JPEG_AMD_OK;
+    if (!d_rect || !d_pixels) return JPEG_AMD_EINVAL;
+    JA_HIP(ctx, launch_unpack(ctx->stream, d_rect, npixels, nplanes, color, d_pixels));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_decode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_images,
+                          const int16_t *const d_coef[], const size_t coef_stride[],
+                          const uint16_t *d_quanta, size_t quanta_stride, int ntables,
+                          int cosited, jpeg_amd_color color, uint8_t *d_pixels,
+                          size_t pixel_stride)
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    JA_TRY(check_planes_cover_image(L));
+    if (n_images < 0 || n_images > 65535) return JPEG_AMD_EINVAL;
+    if (L->nplanes != 1 && L->nplanes != 3) return JPEG_AMD_EINVAL;   // built-in colour formats
+    if (L->precision != 8) return JPEG_AMD_ENOSUP;                   // JPEG.Common is 8-bit
+    if (color != JPEG_AMD_COLOR_YCC8 && color != JPEG_AMD_COLOR_RGB8) return JPEG_AMD_EINVAL;
+    if (n_images == 0) return JPEG_AMD_OK;
+    if (!d_coef || !coef_stride || !d_quanta || !d_pixels) return JPEG_AMD_EINVAL;
+    for (int p = 0; p < L->nplanes; ++p)
+        if (!d_coef[p]) return JPEG_AMD_EINVAL;
+
+    // general path: IDCT every plane into uint8 scratch planes, then upsample + colour.
+    size_t offset[JPEG_AMD_MAX_PLANES], total = 0;
+    for (int p = 0; p < L->nplanes; ++p) {
+        offset[p] = total;
+        total += align256(plane_samples(L, p) * (size_t)n_images);
+    }
+    JA_TRY(ensure_scratch(ctx, total));
+    PlaneSet ps{};
+    for (int p = 0; p < L->nplanes; ++p) {
+        uint8_t *dst = static_cast<uint8_t *>(ctx->scratch) + offset[p];
+        JA_HIP(ctx, launch_idct_plane(ctx->stream, n_images, d_coef[p], coef_stride[p],
+                                      QuantaRef{d_quanta, quanta_stride}, L->qi[p],
+                                      L->units_x[p], L->units_y[p], L->precision, dst,
+                                      plane_samples(L, p), true));
+        ps.ptr[p] = dst;
+        ps.stride[p] = plane_samples(L, p);
+    }
+    JA_HIP(ctx, launch_planar_to_pixels(ctx->stream, n_images, *L, ps, true, cosited != 0,
+                                        color == JPEG_AMD_COLOR_RGB8 ? PixelKind::RGB8 : PixelKind::YCC8,
+                                        d_pixels, pixel_stride));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const int16_t *const d_coef[],
+                    const uint16_t *h_quanta, int ntables, int cosited, jpeg_amd_color color,
+                    uint8_t *d_pixels)
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
+    const size_t zero[JPEG_AMD_MAX_PLANES] = {0, 0, 0, 0};
+    return jpeg_amd_decode_batch(ctx, L, 1, d_coef, zero, d_q, 0, ntables, cosited, color,
+                                 d_pixels, 0);
+}
+
+// ---- encode stages ----------------------------------------------------------------------
+
+int jpeg_amd_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *d_pixels, size_t npixels,
+                              int nplanes, jpeg_amd_color color, uint16_t *d_rect)
+{
+    JA_TRY(bind(ctx));
+    if (nplanes != 1 && nplanes != 3) return JPEG_AMD_EINVAL;
+    if (color != JPEG_AMD_COLOR_YCC8 && color != JPEG_AMD_COLOR_RGB8) return JPEG_AMD_EINVAL;
+    if (npixels == 0) return JPEG_AMD_OK;
+    if (!d_rect || !d_pixels) return JPEG_AMD_EINVAL;
+    JA_HIP(ctx, launch_pack(ctx->stream, d_pixels, npixels, nplanes, color, d_rect));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_rectangular_decomposed(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                                    const uint16_t *d_rect, uint16_t *const d_planes[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, -1));
+    if (!d_rect || !d_planes) return JPEG_AMD_EINVAL;
+    PlaneSetMut ps{};
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (plane_samples(L, p) && !d_planes[p]) return JPEG_AMD_EINVAL;
+        ps.ptr[p] = d_planes[p];
+    }
+    JA_HIP(ctx, launch_decompose(ctx->stream, 1, *L, d_rect, 0, PixelKind::Rect16, ps));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_fdct_plane(jpeg_amd_ctx *ctx, const uint16_t *d_plane, int units_x, int units_y,
+                        const uint16_t h_quanta_zigzag[64], int precision, int16_t *d_coef)
+{
+    JA_TRY(bind(ctx));
+    if (units_x < 0 || units_y < 0 || precision < 1 || precision > 16) return JPEG_AMD_EINVAL;
+    if ((long long)units_x * units_y > (1LL << 30)) return JPEG_AMD_EINVAL;
+    if (units_x == 0 || units_y == 0) return JPEG_AMD_OK;
+    if (!d_coef || !d_plane) return JPEG_AMD_EINVAL;
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta_zigzag, 1, &d_q));
+    JA_HIP(ctx, launch_fdct_plane(ctx->stream, 1, d_plane, 0, QuantaRef{d_q, 0}, 0, units_x,
+                                  units_y, precision, d_coef, 0));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_planar_fdct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                         const uint16_t *const d_planes[], const uint16_t *h_quanta, int ntables,
+                         int16_t *const d_coef[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (!d_coef || !d_planes) return JPEG_AMD_EINVAL;
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (plane_samples(L, p) == 0) continue;
+        if (!d_coef[p] || !d_planes[p]) return JPEG_AMD_EINVAL;
+        JA_HIP(ctx, launch_fdct_plane(ctx->stream, 1, d_planes[p], 0, QuantaRef{d_q, 0}, L->qi[p],
+                                      L->units_x[p], L->units_y[p], L->precision, d_coef[p], 0));
+    }
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_encode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_images,
+                          const uint8_t *d_pixels, size_t pixel_stride, jpeg_amd_color color,
+                          const uint16_t *d_quanta, size_t quanta_stride, int ntables,
+                          int16_t *const d_coef[], const size_t coef_stride[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (n_images < 0 || n_images > 65535) return JPEG_AMD_EINVAL;
+    if (L->nplanes != 1 && L->nplanes != 3) return JPEG_AMD_EINVAL;
+    if (L->precision != 8) return JPEG_AMD_ENOSUP;
+    if (color != JPEG_AMD_COLOR_YCC8 && color != JPEG_AMD_COLOR_RGB8) return JPEG_AMD_EINVAL;
+    if (n_images == 0) return JPEG_AMD_OK;
+    if (!d_coef || !coef_stride || !d_quanta || !d_pixels) return JPEG_AMD_EINVAL;
+
+    size_t offset[JPEG_AMD_MAX_PLANES], total = 0;
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (plane_samples(L, p) && !d_coef[p]) return JPEG_AMD_EINVAL;
+        offset[p] = total;
+        total += align256(plane_samples(L, p) * (size_t)n_images * sizeof(uint16_t));
+    }
+    JA_TRY(ensure_scratch(ctx, total));
+    PlaneSetMut ps{};
+    for (int p = 0; p < L->nplanes; ++p) {
+        ps.ptr[p] = static_cast<uint8_t *>(ctx->scratch) + offset[p];
+        ps.stride[p] = plane_samples(L, p);
+    }
+    JA_HIP(ctx, launch_decompose(ctx->stream, n_images, *L, d_pixels, pixel_stride,
+                                 color == JPEG_AMD_COLOR_RGB8 ? PixelKind::RGB8 : PixelKind::YCC8, ps));
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (plane_samples(L, p) == 0) continue;
+        JA_HIP(ctx, launch_fdct_plane(ctx->stream, n_images, static_cast<const uint16_t *>(ps.ptr[p]),
+                                      ps.stride[p], QuantaRef{d_quanta, quanta_stride}, L->qi[p],
+                                      L->units_x[p], L->units_y[p], L->precision, d_coef[p],
+                                      coef_stride[p]));
+    }
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const uint8_t *d_pixels,
+                    jpeg_amd_color color, const uint16_t *h_quanta, int ntables,
+                    int16_t *const d_coef[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
+    const size_t zero[JPEG_AMD_MAX_PLANES] = {0, 0, 0, 0};
+    return jpeg_amd_encode_batch(ctx, L, 1, d_pixels, 0, color, d_q, 0, ntables, d_coef, zero);
+}
+
+// ---- host-buffer conveniences -------------------------------------------------------------
+
+namespace {
+
+// Small RAII bag of device buffers for the host wrappers.
+struct DeviceBag {
+    jpeg_amd_ctx *ctx;
+    std::vector<void *> ptrs;
+    explicit DeviceBag(jpeg_amd_ctx *c) : ctx(c) {}
+    ~DeviceBag()
+    {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    int alloc(size_t bytes, void **out)
+    {
+        *out = nullptr;
+        if (bytes == 0) bytes = 16;
+        const hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return JPEG_AMD_ENOMEM; }
+        ptrs.push_back(*out);
+        return JPEG_AMD_OK;
+    }
+    int upload(const void *h, size_t bytes, void **out)
+    {
+        JA_TRY(alloc(bytes, out));
+        if (bytes == 0) return JPEG_AMD_OK;
+        if (!h) return JPEG_AMD_EINVAL;
+        JA_HIP(ctx, hipMemcpyAsync(*out, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return JPEG_AMD_OK;
+    }
+    int download(void *h, const void *d, size_t bytes)
+    {
+        if (bytes == 0) return JPEG_AMD_OK;
+        if (!h) return JPEG_AMD_EINVAL;
+        JA_HIP(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return JPEG_AMD_OK;
+    }
+};
+
+size_t rect_samples(const jpeg_amd_layout *L) { return (size_t)L->width * L->height * L->nplanes; }
+
+}  // namespace
+
+int jpeg_amd_host_spectral_idct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                                const int16_t *const h_coef[], const uint16_t *h_quanta,
+                                int ntables, uint16_t *const h_planes[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (!h_coef || !h_planes) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+    uint16_t *d_planes[JPEG_AMD_MAX_PLANES] = {};
+    for (int p = 0; p < L->nplanes; ++p) {
+        const size_t n = plane_samples(L, p);
+        JA_TRY(bag.upload(h_coef[p], n * 2, (void **)&d_coef[p]));
+        JA_TRY(bag.alloc(n * 2, (void **)&d_planes[p]));
+    }
+    JA_TRY(jpeg_amd_spectral_idct(ctx, L, d_coef, h_quanta, ntables, d_planes));
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.download(h_planes[p], d_planes[p], plane_samples(L, p) * 2));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_host_planar_interleaved(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                                     const uint16_t *const h_planes[], int cosited,
+                                     uint16_t *h_rect)
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, -1));
+    if (!h_planes || !h_rect) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    const uint16_t *d_planes[JPEG_AMD_MAX_PLANES] = {};
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.upload(h_planes[p], plane_samples(L, p) * 2, (void **)&d_planes[p]));
+    uint16_t *d_rect = nullptr;
+    JA_TRY(bag.alloc(rect_samples(L) * 2, (void **)&d_rect));
+    JA_TRY(jpeg_amd_planar_interleaved(ctx, L, d_planes, cosited, d_rect));
+    JA_TRY(bag.download(h_rect, d_rect, rect_samples(L) * 2));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_host_rectangular_unpack(jpeg_amd_ctx *ctx, const uint16_t *h_rect, size_t npixels,
+                                     int nplanes, jpeg_amd_color color, uint8_t *h_pixels)
+{
+    JA_TRY(bind(ctx));
+    if (nplanes != 1 && nplanes != 3) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    uint16_t *d_rect = nullptr;
+    uint8_t *d_px = nullptr;
+    JA_TRY(bag.upload(h_rect, npixels * nplanes * 2, (void **)&d_rect));
+    JA_TRY(bag.alloc(npixels * 3, (void **)&d_px));
+    JA_TRY(jpeg_amd_rectangular_unpack(ctx, d_rect, npixels, nplanes, color, d_px));
+    JA_TRY(bag.download(h_pixels, d_px, npixels * 3));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_host_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                         const int16_t *const h_coef[], const uint16_t *h_quanta, int ntables,
+                         int cosited, jpeg_amd_color color, uint8_t *h_pixels)
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (!h_coef || !h_pixels) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.upload(h_coef[p], plane_samples(L, p) * 2, (void **)&d_coef[p]));
+    uint8_t *d_px = nullptr;
+    const size_t nbytes = (size_t)L->width * L->height * 3;
+    JA_TRY(bag.alloc(nbytes, (void **)&d_px));
+    JA_TRY(jpeg_amd_decode(ctx, L, d_coef, h_quanta, ntables, cosited, color, d_px));
+    JA_TRY(bag.download(h_pixels, d_px, nbytes));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_host_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *h_pixels, size_t npixels,
+                                   int nplanes, jpeg_amd_color color, uint16_t *h_rect)
+{
+    JA_TRY(bind(ctx));
+    if (nplanes != 1 && nplanes != 3) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    uint16_t *d_rect = nullptr;
+    uint8_t *d_px = nullptr;
+    JA_TRY(bag.upload(h_pixels, npixels * 3, (void **)&d_px));
+    JA_TRY(bag.alloc(npixels * nplanes * 2, (void **)&d_rect));
+    JA_TRY(jpeg_amd_rectangular_pack(ctx, d_px, npixels, nplanes, color, d_rect));
+    JA_TRY(bag.download(h_rect, d_rect, npixels * nplanes * 2));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_host_rectangular_decomposed(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                                         const uint16_t *h_rect, uint16_t *const h_planes[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, -1));
+    if (!h_rect || !h_planes) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    uint16_t *d_rect = nullptr;
+    JA_TRY(bag.upload(h_rect, rect_samples(L) * 2, (void **)&d_rect));
+    uint16_t *d_planes[JPEG_AMD_MAX_PLANES] = {};
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.alloc(plane_samples(L, p) * 2, (void **)&d_planes[p]));
+    JA_TRY(jpeg_amd_rectangular_decomposed(ctx, L, d_rect, d_planes));
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.download(h_planes[p], d_planes[p], plane_samples(L, p) * 2));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_host_planar_fdct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                              const uint16_t *const h_planes[], const uint16_t *h_quanta,
+                              int ntables, int16_t *const h_coef[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (!h_coef || !h_planes) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    const uint16_t *d_planes[JPEG_AMD_MAX_PLANES] = {};
+    int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int p = 0; p < L->nplanes; ++p) {
+        const size_t n = plane_samples(L, p);
+        JA_TRY(bag.upload(h_planes[p], n * 2, (void **)&d_planes[p]));
+        JA_TRY(bag.alloc(n * 2, (void **)&d_coef[p]));
+    }
+    JA_TRY(jpeg_amd_planar_fdct(ctx, L, d_planes, h_quanta, ntables, d_coef));
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.download(h_coef[p], d_coef[p], plane_samples(L, p) * 2));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_host_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const uint8_t *h_pixels,
+                         jpeg_amd_color color, const uint16_t *h_quanta, int ntables,
+                         int16_t *const h_coef[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (!h_coef || !h_pixels) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    uint8_t *d_px = nullptr;
+    JA_TRY(bag.upload(h_pixels, (size_t)L->width * L->height * 3, (void **)&d_px));
+    int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.alloc(plane_samples(L, p) * 2, (void **)&d_coef[p]));
+    JA_TRY(jpeg_amd_encode(ctx, L, d_px, color, h_quanta, ntables, d_coef));
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.download(h_coef[p], d_coef[p], plane_samples(L, p) * 2));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+// dct.hpp -- device-side 8-point butterflies, zigzag map and table modulation.
+//
+// Arithmetic contract: every statement is ONE IEEE-754 binary32
+// operation in the reference's order.  Translation units including this header MUST be
+// compiled with -ffp-contract=off; the pragma below is a second line of defence.
+//
+// Reference: tayloraswift/jpeg @ 2024_08_07, sources/jpeg/decode.swift, encode.swift.
+#pragma once
+#pragma clang fp contract(off)
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jpeg_amd {
+
+// natural index (8*h + k) -> zigzag index; tabulation of Table.Quantization.z(k:h:)
+// (decode.swift:1289-1298; known-answer table tests/unit/tests.swift:38-48).
+__host__ __device__ constexpr int zigzag_of(int k, int h)
+{
+    const int p = (k + h < 8) ? 1 : 0;
+    const int q = (k + h) & 1;
+    const int a = 72 * (p ^ 1);
+    const int b = 2 * p - 1;
+    const int n = b * (k + h) - 14 * p + 15;
+    const int t = (n * (n + 1)) >> 1;
+    return a + b * t - q * k - (q ^ 1) * h - 1;
+}
+
+// Spectral.Plane.modulate(quanta:scale:) -- decode.swift:3984-4017.
+// q[h][k] = (r[k] * r[h]) * (scale * Float(Q[z(k,h)])), left-associative like Swift's `*`.
+__host__ __device__ inline float modulate_entry(int k, int h, float scale, uint16_t quantum)
+{
+    const float r[8] = {1.0f, 1.387039845f, 1.306562965f, 1.175875602f,
+                        1.0f, 0.785694958f, 0.541196100f, 0.275899379f};
+    const float hv  = r[k] * r[h];
+    const float row = scale * (float)quantum;
+    return hv * row;
+}
+
+// idct8 -- decode.swift:4042-4093.  h[0..7] along the transformed axis.
+// SHIFTED = false is the first pass (shift: 0): the reference's `0 + h0` only ever
+// changes the sign of a zero, which no later operation of the path can observe.
+template <bool SHIFTED>
+__device__ __forceinline__ void idct8(const float (&h)[8], float shift, float (&g)[8])
+{
+    const float e  = SHIFTED ? shift + h[0] : h[0];
+    const float a0 = e + h[4];
+    const float a1 = e - h[4];
+    const float b  = h[2] + h[6];
+    const float c  = 1.414213562f * (h[2] - h[6]) - b;
+
+    const float r0 = a0 + b;
+    const float r1 = a1 + c;
+    const float r2 = a1 - c;
+    const float r3 = a0 - b;
+
+    const float d0 = h[5] - h[3];
+    const float d1 = h[1] + h[7];
+    const float d2 = h[1] - h[7];
+    const float d3 = h[5] + h[3];
+
+    const float f  = 1.414213562f * (d1 - d3);
+    const float l  = 1.847759065f * (d0 + d2);
+    const float m0 = l - d2 * 1.082392200f;
+    const float m1 = l - d0 * 2.613125930f;
+
+    const float s0 = d1 + d3;
+    const float s1 = m1 - s0;
+    const float s2 = f - s1;
+    const float s3 = m0 - s2;
+
+    g[0] = r0 + s0;
+    g[1] = r1 + s1;
+    g[2] = r2 + s2;
+    g[3] = r3 + s3;
+    g[4] = r3 - s3;
+    g[5] = r2 - s2;
+    g[6] = r1 - s1;
+    g[7] = r0 - s0;
+}
+
+// fdct8 -- encode.swift:123-188.  Output order (r0, s0, r1, s1, r2, s2, r3, s3).
+// SHIFTED = false is the second pass (shift: 0): `x - 0` is exact.
+template <bool SHIFTED>
+__device__ __forceinline__ void fdct8(const float (&g)[8], float shift, float (&o)[8])
+{
+    const float a0 = g[0] + g[7];
+    const float a1 = g[1] + g[6];
+    const float a2 = g[2] + g[5];
+    const float a3 = g[3] + g[4];
+
+    const float b0 = a0 + a3;
+    const float b1 = a1 + a2;
+    const float b2 = a1 - a2;
+    const float b3 = a0 - a3;
+
+    const float c  = 0.707106781f * (b2 + b3);
+    const float r0 = SHIFTED ? (b0 + b1) - shift : b0 + b1;
+    const float r1 = b3 + c;
+    const float r2 = b0 - b1;
+    const float r3 = b3 - c;
+
+    const float d0 = g[3] - g[4];
+    const float d1 = g[2] - g[5];
+    const float d2 = g[1] - g[6];
+    const float d3 = g[0] - g[7];
+
+    const float f0 = d0 + d1;
+    const float f1 = d1 + d2;
+    const float f2 = d2 + d3;
+
+    const float k  = 0.707106781f * f1;
+    const float l  = 0.382683433f * (f0 - f2);
+    const float m0 = l + f0 * 0.541196100f;
+    const float m1 = l + f2 * 1.306562965f;
+
+    const float n0 = d3 + k;
+    const float n1 = d3 - k;
+
+    const float s0 = n0 + m1;
+    const float s1 = n1 - m0;
+    const float s2 = n1 + m0;
+    const float s3 = n0 - m1;
+
+    o[0] = r0; o[1] = s0; o[2] = r1; o[3] = s1;
+    o[4] = r2; o[5] = s2; o[6] = r3; o[7] = s3;
+}
+
+// One quantised coefficient out of a block held as 32 packed dwords (zigzag order).
+__device__ __forceinline__ float coef_as_float(const uint32_t (&w)[32], int z)
+{
+    const int32_t word = (int32_t)w[z >> 1];
+    const int32_t c    = (z & 1) ? (word >> 16) : (int32_t)(int16_t)word;
+    return (float)c;
+}
+
+// Spectral.Plane.load + idct8x8 -- decode.swift:4020-4039, 4095-4099.
+// w: 64 int16 in zigzag order; q: modulated table, natural order q[8*h + k] (any address
+// space, uniform across the wave); g[8*y + x]: samples before clamp (level already added).
+template <typename QPtr>
+__device__ __forceinline__ void idct_block(const uint32_t (&w)[32], QPtr q, float level,
+                                           float (&g)[64])
+{
+    float f[64];  // f[8*k + y]: after first pass + transpose
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float h[8], res[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh)
+            h[hh] = q[8 * hh + k] * coef_as_float(w, zigzag_of(k, hh));
+        idct8<false>(h, 0.0f, res);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) f[8 * k + y] = res[y];
+    }
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        float r[8], res[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = f[8 * k + y];
+        idct8<true>(r, level, res);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) g[8 * y + x] = res[x];
+    }
+}
+
+// Planar.Plane.load + fdct8x8 -- encode.swift:80-99, 191-196.
+// g[8*y + x]: samples already min(limit, Float(sample)); out H[8*h + k] before quantise.
+__device__ __forceinline__ void fdct_block(const float (&g)[64], float level, float (&H)[64])
+{
+    float f[64];  // f[8*k + y]
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        float r[8], res[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) r[x] = g[8 * y + x];
+        fdct8<true>(r, level, res);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[8 * k + y] = res[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float r[8], res[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) r[y] = f[8 * k + y];
+        fdct8<false>(r, 0.0f, res);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) H[8 * h + k] = res[h];
+    }
+}
+
+// clamp to [0, limit] then truncate toward zero (decode.swift:4121-4122;
+// SIMD.clamped + SIMD8<UInt16>(_:) ).  Inputs are finite, so med3 == min(max()).
+__device__ __forceinline__ uint32_t clamp_trunc(float v, float limit)
+{
+    return (uint32_t)__builtin_amdgcn_fmed3f(v, 0.0f, limit);
+}
+
+// Float.rounded() / rounding: .toNearestOrAwayFromZero
+__device__ __forceinline__ float round_half_away(float v)
+{
+    return roundf(v);
+}
+
+}  // namespace jpeg_amd

@@ -1,0 +1,66 @@
+// kernels.hpp -- internal launch interface between the C ABI (capi.hip) and the gfx950
+// kernels (kernels_*.hip).  Everything here is device-resident and asynchronous on `stream`.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/jpeg_amd.h"
+
+namespace jpeg_amd {
+
+// Per-plane description of a batch of identically laid out images.
+// image i of plane p lives at ptr[p] + i * stride[p] (elements).
+struct PlaneSet {
+    const void *ptr[JPEG_AMD_MAX_PLANES];
+    size_t      stride[JPEG_AMD_MAX_PLANES];
+};
+struct PlaneSetMut {
+    void  *ptr[JPEG_AMD_MAX_PLANES];
+    size_t stride[JPEG_AMD_MAX_PLANES];
+};
+
+// Quantisation tables in HBM: uint16 [n_images or 1][ntables][64] zigzag.
+struct QuantaRef {
+    const uint16_t *d_quanta;
+    size_t          image_stride;  // uint16 elements between image table sets (0 = shared)
+};
+
+enum class PixelKind : int { Rect16 = 0, YCC8 = 1, RGB8 = 2 };
+
+// ---- decode -------------------------------------------------------------------------
+// a3..a7: dequantise + IDCT of one plane (batch of n_images), output uint16 or uint8 samples.
+hipError_t launch_idct_plane(hipStream_t stream, int n_images, const int16_t *d_coef,
+                             size_t coef_stride, QuantaRef q, int qi, int ux, int uy,
+                             int precision, void *d_plane, size_t plane_stride,
+                             bool out_u8);
+
+// a9 (+ a11/a12): upsample + interleave, written as Rectangular uint16, or colour-converted
+// straight to YCbCr / RGB bytes.  Planes are uint16 (or uint8 when planes_u8).
+hipError_t launch_planar_to_pixels(hipStream_t stream, int n_images,
+                                   const jpeg_amd_layout &layout, const PlaneSet &planes,
+                                   bool planes_u8, bool cosited, PixelKind kind,
+                                   void *d_out, size_t out_stride_bytes);
+
+// a10..a12: Rectangular.unpack(as:) for YCbCr / RGB.
+hipError_t launch_unpack(hipStream_t stream, const uint16_t *d_rect, size_t npixels,
+                         int nplanes, jpeg_amd_color color, uint8_t *d_pixels);
+
+// ---- encode -------------------------------------------------------------------------
+// a13: Rectangular.pack
+hipError_t launch_pack(hipStream_t stream, const uint8_t *d_pixels, size_t npixels,
+                       int nplanes, jpeg_amd_color color, uint16_t *d_rect);
+
+// a14: Rectangular.decomposed() for every plane; input is Rectangular uint16, or pixel
+// bytes (RGB8 / YCC8) colour-converted on the fly.
+hipError_t launch_decompose(hipStream_t stream, int n_images, const jpeg_amd_layout &layout,
+                            const void *d_in, size_t in_stride_bytes, PixelKind in_kind,
+                            const PlaneSetMut &planes);
+
+// a15..a17: FDCT + quantise of one plane.
+hipError_t launch_fdct_plane(hipStream_t stream, int n_images, const uint16_t *d_plane,
+                             size_t plane_stride, QuantaRef q, int qi, int ux, int uy,
+                             int precision, int16_t *d_coef, size_t coef_stride);
+
+}  // namespace jpeg_amd

@@ -1,0 +1,298 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors.  Bit-exact on every output integer -- tolerance 0."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def J():
+    import jpeg_amd
+    return jpeg_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(J):
+    return J.Context(0)
+
+
+def _layout_for(J, img):
+    n = len(img.components)
+    fmt = "y8" if n == 1 else "ycc8"
+    comps = {c.ident: J.Component((c.fx, c.fy), i) for i, c in enumerate(img.components)}
+    return J.Layout(fmt, comps)
+
+
+def _spectral(J, ctx, img):
+    layout = _layout_for(J, img)
+    return J.Spectral.from_host(ctx, (img.width, img.height), layout, img.planes, img.quanta,
+                                q=list(range(len(img.components))))
+
+
+# ---- config 2: 100k synthetic blocks, IDCT + dequant only ---------------------------------
+
+@pytest.mark.parametrize("dist", ["uniform", "natural"])
+@pytest.mark.parametrize("table", ["ones", "luminance1.0"])
+def test_c2_100k_blocks_idct(J, ctx, dist, table):
+    from jpeg_amd import synth
+    blocks = (synth.blocks_uniform if dist == "uniform" else synth.blocks_natural)(100_000)
+    coef = blocks.reshape(250, 400, 64)
+    q = np.ones(64, np.uint16) if table == "ones" else J.compression_quanta("luminance", 1.0)
+    layout = J.Layout("y8", {1: J.Component((1, 1), 0)})
+    spectral = J.Spectral.from_host(ctx, (3200, 2000), layout, [coef], [q])
+    got = spectral.idct().host_planes()[0]
+    want = O.idct_plane(coef, q, 8, threads=8)
+    assert got.shape == want.shape
+    assert (got == want).all(), f"{(got != want).sum()} of {got.size} samples differ"
+
+
+# ---- staged decode on every fixture ---------------------------------------------------------
+
+@pytest.mark.parametrize("name", G.decode_names())
+def test_staged_decode_matches_oracle_and_gold(J, ctx, name):
+    img = G.image(name)
+    n = len(img.components)
+    spectral = _spectral(J, ctx, img)
+    planar_o, rect_o = O.decode(img.planes, img.quanta, img.factors, (img.width, img.height))
+
+    planar = spectral.idct()
+    for got, want in zip(planar.host_planes(), planar_o):
+        assert (got == want).all()
+    rect = planar.interleaved(cosite=False)
+    assert (rect.host_values() == rect_o).all()
+    ycc = rect.unpack(J.YCbCr).cpu().numpy()
+    rgb = rect.unpack(J.RGB).cpu().numpy()
+    assert (ycc == O.unpack_ycc8(rect_o, n)).all()
+    assert (rgb == O.unpack_rgb8(rect_o, n)).all()
+    gold = G.entry(name)["gold"]
+    if "ycc_sha256" in gold:
+        assert G.sha(ycc) == gold["ycc_sha256"]
+    if "rgb_sha256" in gold:
+        assert G.sha(rgb) == gold["rgb_sha256"]
+
+
+@pytest.mark.parametrize("name", G.decode_names())
+@pytest.mark.parametrize("color", ["rgb", "ycc"])
+def test_fused_decode_matches_gold(J, ctx, name, color):
+    img = G.image(name)
+    n = len(img.components)
+    spectral = _spectral(J, ctx, img)
+    got = spectral.decode(J.RGB if color == "rgb" else J.YCbCr).cpu().numpy()
+    _, rect_o = O.decode(img.planes, img.quanta, img.factors, (img.width, img.height))
+    want = (O.unpack_rgb8 if color == "rgb" else O.unpack_ycc8)(rect_o, n)
+    assert (got == want).all(), f"{(got != want).sum()} bytes differ"
+    gold = G.entry(name)["gold"]
+    if color + "_sha256" in gold:
+        assert G.sha(got) == gold[color + "_sha256"]
+
+
+def test_idct_stage_planes_match_decode_advanced_dump(J, ctx):
+    img = G.image("karlie-2019.jpg")
+    planes = _spectral(J, ctx, img).idct().host_planes()
+    for p, g in enumerate(G.entry("karlie-2019.jpg")["gold"]["planes"]):
+        want = np.fromfile(G.path(g["file"]), np.uint8)
+        assert (planes[p].astype(np.uint8).reshape(-1) == want).all()
+
+
+# ---- cosited + unusual layouts (no gold in the reference: oracle is the checker) ------------
+
+LAYOUTS = [
+    # (size, [(factor, qi)...] recognised, extra non-recognised factor or None, precision)
+    ((1, 1), [((1, 1), 0)], None, 8),
+    ((7, 9), [((2, 2), 0), ((1, 1), 1), ((1, 1), 1)], None, 8),
+    ((17, 33), [((2, 1), 0), ((1, 1), 1), ((1, 1), 1)], None, 8),
+    ((33, 17), [((1, 2), 0), ((1, 1), 1), ((1, 1), 1)], None, 8),
+    ((50, 41), [((4, 1), 0), ((1, 1), 1), ((1, 1), 1)], None, 8),     # 4:1:1
+    ((45, 37), [((3, 2), 0), ((1, 1), 1), ((3, 1), 1)], None, 8),     # odd factors
+    ((40, 24), [((1, 1), 0), ((1, 1), 1), ((1, 1), 1)], (2, 2), 8),   # scale from a non-recognised comp
+    ((37, 29), [((2, 2), 0), ((1, 1), 1), ((1, 1), 1), ((2, 1), 0)], None, 12),  # custom 4-plane 12-bit
+]
+
+
+def _random_spectral(J, ctx, size, comps, extra, precision, seed):
+    rng = np.random.default_rng(seed)
+    keyed = {i + 1: J.Component(f, qi) for i, (f, qi) in enumerate(comps)}
+    if extra is not None:
+        keyed[99] = J.Component(extra, 0)
+    n = len(comps)
+    fmt = "y8" if (n == 1 and precision == 8) else "ycc8" if (n == 3 and precision == 8) else ("custom", precision, n)
+    layout = J.Layout(fmt, keyed)
+    units = layout.units(size)
+    amp = 1 << (precision + 1)
+    planes = []
+    for ux, uy in units:
+        c = rng.integers(-amp, amp, (uy, ux, 64)).astype(np.int16)
+        c[..., 8:] //= 8
+        planes.append(c)
+    nq = max(qi for _, qi in comps) + 1
+    quanta = [rng.integers(1, 40, 64).astype(np.uint16) for _ in range(nq)]
+    q = [qi for _, qi in comps]
+    return layout, planes, quanta, q
+
+
+@pytest.mark.parametrize("case", range(len(LAYOUTS)))
+@pytest.mark.parametrize("cosite", [False, True])
+def test_staged_decode_unusual_layouts(J, ctx, case, cosite):
+    size, comps, extra, precision = LAYOUTS[case]
+    layout, planes, quanta, q = _random_spectral(J, ctx, size, comps, extra, precision, 100 + case)
+    spectral = J.Spectral.from_host(ctx, size, layout, planes, quanta, q=q)
+    planar = spectral.idct()
+    factors = [c.factor for c in layout.planes]
+    planar_o = [O.idct_plane(p, quanta[qi], precision) for p, qi in zip(planes, q)]
+    for got, want in zip(planar.host_planes(), planar_o):
+        assert (got == want).all()
+    rect = planar.interleaved(cosite=cosite).host_values()
+    want = O.interleave(planar_o, factors, layout.scale, size, cosited=cosite)
+    assert (rect == want).all(), f"{(rect != want).sum()} samples differ"
+    if precision == 8 and len(comps) in (1, 3):
+        for color, unpack in ((J.RGB, O.unpack_rgb8), (J.YCbCr, O.unpack_ycc8)):
+            got = spectral.decode(color, cosite=cosite).cpu().numpy()
+            assert (got == unpack(want, len(comps))).all()
+
+
+# ---- encode ------------------------------------------------------------------------------------
+
+def _encode_layout(J, factors):
+    return J.Layout("ycc8", {1: J.Component(tuple(factors[0]), 0),
+                             2: J.Component(tuple(factors[1]), 1),
+                             3: J.Component(tuple(factors[2]), 1)})
+
+
+@pytest.mark.parametrize("case", G.encode_cases(), ids=lambda c: f"{c['mode']}-{c['level']}")
+def test_encode_matches_reference_coefficients(J, ctx, case):
+    rgb, size = G.encode_source()
+    layout = _encode_layout(J, case["factors"])
+    quanta = {0: J.compression_quanta("luminance", case["level"]),
+              1: J.compression_quanta("chrominance", case["level"])}
+    # staged: pack -> decomposed -> fdct
+    rect = J.Rectangular.pack(ctx, size, layout, rgb, J.RGB)
+    spectral = rect.decomposed().fdct(quanta)
+    assert [G.sha(p) for p in spectral.host_planes()] == case["coef_sha256"]
+    # fused
+    fused = J.Rectangular.encode(ctx, size, layout, rgb, quanta, J.RGB)
+    assert [G.sha(p) for p in fused.host_planes()] == case["coef_sha256"]
+
+
+def test_encode_stages_match_oracle(J, ctx):
+    rgb, size = G.encode_source()
+    factors = [(2, 2), (1, 1), (1, 1)]
+    layout = _encode_layout(J, factors)
+    rect = J.Rectangular.pack(ctx, size, layout, rgb, J.RGB)
+    want_rect = O.pack_rgb8(rgb, 3).reshape(size[1], size[0], 3)
+    assert (rect.host_values() == want_rect).all()
+    planar = rect.decomposed()
+    want_planes = O.decompose(want_rect, size, factors, (2, 2))
+    for got, want in zip(planar.host_planes(), want_planes):
+        assert (got == want).all()
+    # YCbCr pack is a widening copy
+    ycc = O.unpack_ycc8(want_rect, 3)
+    rect2 = J.Rectangular.pack(ctx, size, layout, ycc, J.YCbCr)
+    assert (rect2.host_values() == want_rect).all()
+
+
+@pytest.mark.parametrize("case", [1, 2, 4, 5])
+def test_encode_unusual_layouts(J, ctx, case):
+    size, comps, extra, precision = LAYOUTS[case]
+    rng = np.random.default_rng(7 + case)
+    rgb = rng.integers(0, 256, (size[0] * size[1], 3)).astype(np.uint8)
+    layout = J.Layout("ycc8", {i + 1: J.Component(f, qi) for i, (f, qi) in enumerate(comps)})
+    factors = [c.factor for c in layout.planes]
+    quanta = {0: rng.integers(1, 30, 64).astype(np.uint16), 1: rng.integers(1, 30, 64).astype(np.uint16)}
+    want = O.encode(rgb, size, factors, [quanta[qi] for _, qi in comps], scale=layout.scale)
+    got = J.Rectangular.pack(ctx, size, layout, rgb, J.RGB).decomposed().fdct(quanta).host_planes()
+    for a, b in zip(got, want):
+        assert (a == b).all()
+    fused = J.Rectangular.encode(ctx, size, layout, rgb, quanta, J.RGB).host_planes()
+    for a, b in zip(fused, want):
+        assert (a == b).all()
+
+
+def test_fdct_idct_roundtrip_property(J, ctx):
+    """encode -> decode round trip with all-ones quanta reproduces the image within 1 LSB
+    per YCbCr sample (size-independent property; no oracle involved)."""
+    from jpeg_amd import synth
+    size = (256, 192)
+    rgb = synth.smooth_rgb(*size)
+    layout = _encode_layout(J, [(1, 1), (1, 1), (1, 1)])
+    ones = {0: np.ones(64, np.uint16), 1: np.ones(64, np.uint16)}
+    spectral = J.Rectangular.encode(ctx, size, layout, rgb, ones, J.RGB)
+    ycc_back = spectral.decode(J.YCbCr).cpu().numpy().astype(int)
+    ycc_in = J.Rectangular.pack(ctx, size, layout, rgb, J.RGB).unpack(J.YCbCr).cpu().numpy().astype(int)
+    assert np.abs(ycc_back - ycc_in).max() <= 1
+
+
+# ---- error behaviour + host-buffer ABI ---------------------------------------------------------
+
+def test_precondition_failures_come_back_as_einval(J, ctx):
+    from jpeg_amd import _lib
+    layout = J.Layout("ycc8", {1: J.Component((1, 1), 0), 2: J.Component((1, 1), 0), 3: J.Component((1, 1), 0)})
+    with pytest.raises(J.JpegAmdError) as e:   # decode.swift:1710 array count does not match
+        J.Rectangular.from_host(ctx, (4, 4), layout, np.zeros(5, np.uint16))
+    assert e.value.status == _lib.EINVAL
+    planar = J.Planar.from_host(ctx, (8, 8), layout, [np.zeros((8, 8), np.uint16)] * 3)
+    with pytest.raises(J.JpegAmdError):        # decode.swift:2527 missing quantization table
+        planar.fdct({7: np.ones(64, np.uint16)})
+    L = layout.c_layout((0, 8))
+    st = _lib.lib().jpeg_amd_planar_interleaved(ctx.handle, C.byref(L), _lib.ptr_array([1, 1, 1]), 0, 1)
+    assert st == _lib.EINVAL                   # decode.swift:2599 size must be positive
+
+
+def test_host_buffer_abi(J, ctx):
+    """jpeg_amd_host_* (what the Swift shim binds): host pointers in, host pointers out."""
+    from jpeg_amd import _lib
+    img = G.image("color-sequential-1.jpg")
+    layout = _layout_for(J, img)
+    size = (img.width, img.height)
+    L = layout.c_layout(size, [(c.ux, c.uy) for c in img.components], [0, 1, 2])
+    q = np.ascontiguousarray(np.stack(img.quanta).astype(np.uint16))
+    coef = [np.ascontiguousarray(p) for p in img.planes]
+    out = np.empty((img.width * img.height, 3), np.uint8)
+    lib = _lib.lib()
+    st = lib.jpeg_amd_host_decode(ctx.handle, C.byref(L), _lib.ptr_array([c.ctypes.data for c in coef]),
+                                  q.ctypes.data, 3, 0, _lib.COLOR_RGB8, out.ctypes.data)
+    assert st == 0
+    assert G.sha(out) == G.entry("color-sequential-1.jpg")["gold"]["rgb_sha256"]
+
+    planes = [np.empty((8 * c.uy, 8 * c.ux), np.uint16) for c in img.components]
+    st = lib.jpeg_amd_host_spectral_idct(ctx.handle, C.byref(L), _lib.ptr_array([c.ctypes.data for c in coef]),
+                                         q.ctypes.data, 3, _lib.ptr_array([p.ctypes.data for p in planes]))
+    assert st == 0
+    rect = np.empty((img.height, img.width, 3), np.uint16)
+    st = lib.jpeg_amd_host_planar_interleaved(ctx.handle, C.byref(L), _lib.ptr_array([p.ctypes.data for p in planes]),
+                                              0, rect.ctypes.data)
+    assert st == 0
+    ycc = np.empty((img.width * img.height, 3), np.uint8)
+    st = lib.jpeg_amd_host_rectangular_unpack(ctx.handle, rect.ctypes.data, img.width * img.height, 3,
+                                              _lib.COLOR_YCC8, ycc.ctypes.data)
+    assert st == 0
+    assert G.sha(ycc) == G.entry("color-sequential-1.jpg")["gold"]["ycc_sha256"]
+
+    # encode side
+    rgb, esize = G.encode_source()
+    case = next(c for c in G.encode_cases() if c["mode"] == "4-2-0" and c["level"] == 1.0)
+    elay = _encode_layout(J, case["factors"])
+    EL = elay.c_layout(esize, None, [0, 1, 1])
+    eq = np.ascontiguousarray(np.stack([J.compression_quanta("luminance", 1.0),
+                                        J.compression_quanta("chrominance", 1.0)]))
+    ecoef = [np.empty((uy, ux, 64), np.int16) for ux, uy in elay.units(esize)]
+    st = lib.jpeg_amd_host_encode(ctx.handle, C.byref(EL), np.ascontiguousarray(rgb).ctypes.data, _lib.COLOR_RGB8,
+                                  eq.ctypes.data, 2, _lib.ptr_array([c.ctypes.data for c in ecoef]))
+    assert st == 0
+    assert [G.sha(c) for c in ecoef] == case["coef_sha256"]
+    # staged host encode
+    erect = np.empty((esize[1], esize[0], 3), np.uint16)
+    assert lib.jpeg_amd_host_rectangular_pack(ctx.handle, np.ascontiguousarray(rgb).ctypes.data, esize[0] * esize[1], 3,
+                                              _lib.COLOR_RGB8, erect.ctypes.data) == 0
+    eplanes = [np.empty((8 * uy, 8 * ux), np.uint16) for ux, uy in elay.units(esize)]
+    assert lib.jpeg_amd_host_rectangular_decomposed(ctx.handle, C.byref(EL), erect.ctypes.data,
+                                                    _lib.ptr_array([p.ctypes.data for p in eplanes])) == 0
+    ecoef2 = [np.empty((uy, ux, 64), np.int16) for ux, uy in elay.units(esize)]
+    assert lib.jpeg_amd_host_planar_fdct(ctx.handle, C.byref(EL), _lib.ptr_array([p.ctypes.data for p in eplanes]),
+                                         eq.ctypes.data, 2, _lib.ptr_array([c.ctypes.data for c in ecoef2])) == 0
+    assert [G.sha(c) for c in ecoef2] == case["coef_sha256"]

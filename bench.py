@@ -1,0 +1,368 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X spectral pipeline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c5] [--no-extras]
+
+Metric (BASELINE.json): Mpixels/s of device-resident fused decode
+(dequant + IDCT + 4:2:0 upsample + YCbCr->RGB), and its fraction of the HBM roofline.
+A step = one pass of jpeg_amd_decode_batch over one batch of synthetic coefficient planes
+already resident in HBM (host Huffman decoding and PCIe transfers are out of scope and
+excluded; see DESIGN.md "Measurement").
+
+Workload c3 (default, BASELINE.json configs[2]): one 8192x8192 ycc8 4:2:0 image per GPU per
+step; the step rotates through a ring of distinct images so that the 256 MiB Infinity
+Cache cannot serve the input.  Workload c5 (configs[4]): 512 images of 1920x1080 per GPU
+per step (= 4096 images over 8 GPUs).  Scaling is weak: every rank decodes its own
+independent images, there is no data-path collective; the only collective is an RCCL
+broadcast of the quantisation tables from rank 0 before the timed region.
+
+For N > 1 launch with:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_COPY_CEILING_GBS = 6290.0  # measured float4 copy ceiling, same guide
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--ring", type=int, default=0, help="distinct image sets to rotate through")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C2/C4/C5 side measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+class DecodeWorkload:
+    """Fused decode of `n_images` identically laid out ycc8 4:2:0 images per step."""
+
+    def __init__(self, J, ctx, width, height, n_images, ring, quanta, seed):
+        import torch
+        from jpeg_amd import synth, _lib
+        self.J, self.ctx, self._lib = J, ctx, _lib
+        self.size = (width, height)
+        self.n_images, self.ring = n_images, ring
+        self.layout = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1),
+                                        3: J.Component((1, 1), 1)})
+        self.units = self.layout.units(self.size)
+        self.L = self.layout.c_layout(self.size, self.units, [0, 1, 1])
+        dev = ctx.torch_device
+        # ring * n_images images per plane, distribution N
+        self.planes = synth.natural_planes_torch(self.units, ring * n_images, dev, seed)
+        self.stride = [64 * ux * uy for ux, uy in self.units]
+        self.pixel_stride = width * height * 3
+        self.out = torch.empty((ring * n_images, self.pixel_stride), dtype=torch.uint8, device=dev)
+        self.d_quanta = quanta            # device tensor int16 view of uint16 [2][64]
+        self.blocks = sum(ux * uy for ux, uy in self.units)
+        self.pixels = width * height * n_images
+        # algorithmic bytes per step: coefficients in + RGB8 out
+        self.bytes = (128 * self.blocks + 3 * width * height) * n_images
+        self._args = []
+        for r in range(ring):
+            ptrs = _lib.ptr_array([p[r * n_images].data_ptr() for p in self.planes])
+            self._args.append((ptrs, self.out[r * n_images].data_ptr()))
+        self._strides = _lib.size_array(self.stride)
+        self._fn = _lib.lib().jpeg_amd_decode_batch
+        self._step = 0
+
+    def step(self):
+        ptrs, out = self._args[self._step % self.ring]
+        self._step += 1
+        st = self._fn(self.ctx.handle, C.byref(self.L), self.n_images, ptrs, self._strides,
+                      self.d_quanta.data_ptr(), 0, 2, 0, self._lib.COLOR_RGB8, out,
+                      self.pixel_stride)
+        if st != 0:
+            raise self._lib.JpegAmdError(st, "jpeg_amd_decode_batch", 0)
+
+    def check(self, O, quanta_np, image=0, max_rows=None):
+        """Bit-exact check of one output image against the CPU oracle (not timed)."""
+        import numpy as np
+        planes = [p[image].cpu().numpy() for p in self.planes]
+        _, rect = O.decode(planes, [quanta_np[0], quanta_np[1], quanta_np[1]],
+                           [(2, 2), (1, 1), (1, 1)], self.size, threads=min(64, os.cpu_count() or 1))
+        want = O.unpack_rgb8(rect, 3, threads=min(64, os.cpu_count() or 1))
+        got = self.out[image].cpu().numpy().reshape(-1, 3)
+        return bool((got == want).all())
+
+
+def time_region(ctx, fn, steps, sync, barrier):
+    """Barrier + synchronize on both sides; returns (wall seconds, GPU-event ms)."""
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    ctx.timer_begin()
+    for _ in range(steps):
+        fn()
+    gpu_ms = ctx.timer_end()
+    sync()
+    barrier()
+    return time.perf_counter() - t0, gpu_ms
+
+
+def cpu_baseline(O, J, quanta_np, seconds):
+    """Time the oracle (C restatement of the reference's CPU algorithm) on this host:
+    same workload shape (ycc8 4:2:0 fused decode to RGB8), bounded sample."""
+    import numpy as np
+    from jpeg_amd import synth
+
+    def make(w, h):
+        layout = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+        units = layout.units((w, h))
+        planes = [synth.blocks_natural(ux * uy, 11 + i).reshape(uy, ux, 64) for i, (ux, uy) in enumerate(units)]
+        return planes
+
+    def run(planes, size, threads):
+        t0 = time.perf_counter()
+        _, rect = O.decode(planes, [quanta_np[0], quanta_np[1], quanta_np[1]],
+                           [(2, 2), (1, 1), (1, 1)], size, threads=threads)
+        O.unpack_rgb8(rect, 3, threads=threads)
+        return time.perf_counter() - t0
+
+    probe = (512, 512)
+    p = make(*probe)
+    run(p, probe, 1)
+    t = run(p, probe, 1)
+    rate1 = probe[0] * probe[1] / t                          # px/s, one thread
+    side = int(min(8192, max(512, (rate1 * seconds) ** 0.5)) // 16 * 16)
+    size = (side, side)
+    planes = make(*size)
+    t1 = run(planes, size, 1)
+    ncores = os.cpu_count() or 1
+    threads = min(ncores, 64)
+    run(planes, size, threads)
+    tn = run(planes, size, threads)
+    mpx = size[0] * size[1] / 1e6
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        model = "unknown"
+    return {
+        "value": round(mpx / t1, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": f"one {size[0]}x{size[1]} ycc8 4:2:0 image, distribution N, fused decode to RGB8 "
+                  f"(oracle/jpeg_oracle.c, gcc -O2 -ffp-contract=off), {t1:.2f} s",
+        "all_cores": {"value": round(mpx / tn, 3), "cores": threads, "seconds": round(tn, 3)},
+        "host": {"model": model, "nproc": ncores},
+        "note": "C restatement of tayloraswift/jpeg's CPU algorithm (the Swift toolchain is absent); "
+                "a reported baseline, not the optimisation target",
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import jpeg_amd as J
+    from jpeg_amd import _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with python -m torch.distributed.run (see module docstring)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+
+    ctx = J.Context(local)
+
+    # quantisation tables: rank 0 owns them, RCCL broadcast over xGMI is the only collective
+    q_np = np.stack([J.compression_quanta("luminance", 1.0), J.compression_quanta("chrominance", 1.0)])
+    if rank == 0:
+        d_quanta = torch.from_numpy(q_np.view(np.int16)).to(dev)
+    else:
+        d_quanta = torch.zeros((2, 64), dtype=torch.int16, device=dev)
+    if dist is not None:
+        dist.broadcast(d_quanta, src=0)
+        assert (d_quanta.cpu().numpy().view(np.uint16) == q_np).all()
+
+    if args.workload == "c3":
+        ring = args.ring or 8
+        wl = DecodeWorkload(J, ctx, 8192, 8192, 1, ring, d_quanta, seed=20240807 + 1000 * rank)
+        name = ("C3: one 8192x8192 ycc8 4:2:0 image per GPU per step, fused Spectral->RGB8 decode "
+                f"(ring of {ring} distinct images)")
+    else:
+        ring = args.ring or 2
+        wl = DecodeWorkload(J, ctx, 1920, 1080, 512, ring, d_quanta, seed=20240807 + 1000 * rank)
+        name = ("C5: 512 images of 1920x1080 ycc8 4:2:0 per GPU per step, fused Spectral->RGB8 decode "
+                f"(ring of {ring} distinct batches)")
+
+    for _ in range(args.warmup):
+        wl.step()
+    wall, gpu_ms = time_region(ctx, wl.step, args.steps, sync, barrier)
+
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+
+    result = None
+    if rank == 0:
+        total_px = wl.pixels * args.steps * world
+        value = total_px / wall_max / 1e6
+        gpu_s_per_step = gpu_ms / 1e3 / args.steps
+        achieved = wl.bytes / gpu_s_per_step / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload:
+                    traffic = tj.get("hbm_bytes_per_step")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mpixels/s decode (IDCT+dequant+upsample+YCbCr->RGB); % HBM roofline",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall_max / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "image": list(wl.size), "images_per_gpu_per_step": wl.n_images,
+                       "sampling": "4:2:0", "output": "RGB8", "coefficients": "distribution N (SURVEY 8d), seeded",
+                       "quanta": "CompressionLevel luminance/chrominance(1.0)",
+                       "parallelism": f"independent images x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_step": wl.bytes,
+                         "gpu_ms_per_step_hip_events": round(gpu_s_per_step * 1e3, 5),
+                         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
+                         "kernels": "all kernels of one fused decode step (rank 0)"},
+        }
+
+    # ---- not timed: parity of what was just measured, side measurements, CPU baseline ----
+    if rank == 0:
+        from oracle import oracle as O
+        if args.workload == "c5":
+            result["parity_vs_oracle"] = wl.check(O, q_np, image=0)
+        else:
+            # full 8192^2 oracle decode takes a while even threaded: check it anyway, once
+            result["parity_vs_oracle"] = wl.check(O, q_np, image=0)
+        if world == 1 and not args.no_extras:
+            result["extra"] = extras(J, ctx, d_quanta, q_np, sync, args)
+        if world == 1 and not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(O, J, q_np, args.cpu_seconds)
+            result["gpu_over_cpu_1core"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+        print(json.dumps(result), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def extras(J, ctx, d_quanta, q_np, sync, args):
+    """Short side measurements of the other BASELINE.json configurations (N = 1 only)."""
+    import numpy as np
+    import torch
+    from jpeg_amd import synth, _lib
+    out = {}
+    dev = ctx.torch_device
+    lib = _lib.lib()
+
+    # C2-shaped: IDCT + dequant only, 2^22 blocks (bandwidth figure; the 100k-block
+    # bit-exactness check is tests/test_gpu_parity.py::test_c2_100k_blocks_idct)
+    ux, uy = 2048, 2048
+    ring = 3
+    coef = synth.natural_planes_torch([(ux, uy)], ring, dev, 99)[0]
+    plane = torch.empty((ring, 64 * ux * uy), dtype=torch.int16, device=dev)
+    q = np.ascontiguousarray(q_np[0])
+
+    def idct_step(i=[0]):
+        r = i[0] % ring
+        i[0] += 1
+        st = lib.jpeg_amd_idct_plane(ctx.handle, coef[r].data_ptr(), ux, uy, q.ctypes.data, 8, plane[r].data_ptr())
+        assert st == 0
+    for _ in range(5):
+        idct_step()
+    sync()
+    ctx.timer_begin()
+    n = 30
+    for _ in range(n):
+        idct_step()
+    ms = ctx.timer_end() / n
+    nb = ux * uy
+    out["c2_idct_dequant_only"] = {
+        "blocks": nb, "ms": round(ms, 4), "Gblocks_per_s": round(nb / ms / 1e6, 2),
+        "Mpixels_per_s": round(64 * nb / ms / 1e3, 1),
+        "GB_per_s": round(256 * nb / ms / 1e6, 1), "frac_hbm": round(256 * nb / ms / 1e6 / HBM_PEAK_GBS, 4),
+        "bytes_per_block": 256}
+    del coef, plane
+
+    # C4: encode 4096x4096 RGB8 -> 4:2:0 coefficients (fused pack + decomposed + fdct)
+    w = h = 4096
+    ring = 3
+    px = synth.smooth_rgb_torch(w, h, ring, dev)
+    layout = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    units = layout.units((w, h))
+    L = layout.c_layout((w, h), units, [0, 1, 1])
+    coefs = [torch.empty((ring, 64 * a * b), dtype=torch.int16, device=dev) for a, b in units]
+    zero = _lib.size_array([0, 0, 0])
+
+    def enc_step(i=[0]):
+        r = i[0] % ring
+        i[0] += 1
+        st = lib.jpeg_amd_encode_batch(ctx.handle, C.byref(L), 1, px[r].data_ptr(), 0, _lib.COLOR_RGB8,
+                                       d_quanta.data_ptr(), 0, 2, _lib.ptr_array([c[r].data_ptr() for c in coefs]), zero)
+        assert st == 0
+    for _ in range(3):
+        enc_step()
+    sync()
+    ctx.timer_begin()
+    n = 20
+    for _ in range(n):
+        enc_step()
+    ms = ctx.timer_end() / n
+    nbytes = 3 * w * h + 128 * sum(a * b for a, b in units)
+    out["c4_encode_4096"] = {"ms": round(ms, 4), "Mpixels_per_s": round(w * h / ms / 1e3, 1),
+                             "GB_per_s": round(nbytes / ms / 1e6, 1),
+                             "frac_hbm": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    del px, coefs
+
+    # C5-shaped batch on one GPU: 128 images of 1920x1080 (a quarter of the per-GPU share)
+    if args.workload != "c5":
+        wl = DecodeWorkload(J, ctx, 1920, 1080, 128, 2, d_quanta, seed=5)
+        for _ in range(2):
+            wl.step()
+        sync()
+        ctx.timer_begin()
+        n = 10
+        for _ in range(n):
+            wl.step()
+        ms = ctx.timer_end() / n
+        out["c5_batch_128x1080p"] = {"ms": round(ms, 4), "Mpixels_per_s": round(wl.pixels / ms / 1e3, 1),
+                                     "GB_per_s": round(wl.bytes / ms / 1e6, 1),
+                                     "frac_hbm": round(wl.bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -358,6 +358,15 @@ int jpeg_amd_decode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_ima
     for (int p = 0; p < L->nplanes; ++p)
         if (!d_coef[p]) return JPEG_AMD_EINVAL;
 
+    if (fused_decode_supported(*L, cosited != 0)) {
+        JA_TRY(ensure_scratch(ctx, fused_decode_scratch_bytes(*L, n_images)));
+        PlaneSet cs{};
+        for (int p = 0; p < L->nplanes; ++p) { cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p]; }
+        JA_HIP(ctx, launch_fused_decode(ctx->stream, n_images, *L, cs, QuantaRef{d_quanta, quanta_stride},
+                                        color == JPEG_AMD_COLOR_RGB8, ctx->scratch, d_pixels, pixel_stride));
+        return JPEG_AMD_OK;
+    }
+
     // general path: IDCT every plane into uint8 scratch planes, then upsample + colour.
     size_t offset[JPEG_AMD_MAX_PLANES], total = 0;
     for (int p = 0; p < L->nplanes; ++p) {

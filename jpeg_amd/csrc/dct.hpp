@@ -163,6 +163,32 @@ __device__ __forceinline__ void idct_block(const uint32_t (&w)[32], QPtr q, floa
     }
 }
 
+// The same two passes, split so that a kernel can interleave other work between them and
+// produce output rows one at a time (idct_block == idct_pass1 + 8 x idct_pass2_row).
+template <typename QPtr>
+__device__ __forceinline__ void idct_pass1(const uint32_t (&w)[32], QPtr q, float (&f)[64])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float h[8], res[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh)
+            h[hh] = q[8 * hh + k] * coef_as_float(w, zigzag_of(k, hh));
+        idct8<false>(h, 0.0f, res);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) f[8 * k + y] = res[y];
+    }
+}
+
+__device__ __forceinline__ void idct_pass2_row(const float (&f)[64], int y, float level,
+                                               float (&g)[8])
+{
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = f[8 * k + y];
+    idct8<true>(r, level, g);
+}
+
 // Planar.Plane.load + fdct8x8 -- encode.swift:80-99, 191-196.
 // g[8*y + x]: samples already min(limit, Float(sample)); out H[8*h + k] before quantise.
 __device__ __forceinline__ void fdct_block(const float (&g)[64], float level, float (&H)[64])

@@ -47,6 +47,14 @@ hipError_t launch_planar_to_pixels(hipStream_t stream, int n_images,
 hipError_t launch_unpack(hipStream_t stream, const uint16_t *d_rect, size_t npixels,
                          int nplanes, jpeg_amd_color color, uint8_t *d_pixels);
 
+// Fused Spectral -> YCbCr / RGB bytes (kernels_fused.hip): 8-bit y8 images, and ycc8 images
+// with full-factor luma and 1x / 2x subsampled chroma, centred upsampling.
+bool       fused_decode_supported(const jpeg_amd_layout &layout, bool cosited);
+size_t     fused_decode_scratch_bytes(const jpeg_amd_layout &layout, int n_images);
+hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &layout,
+                               const PlaneSet &coef, QuantaRef q, bool rgb, void *scratch,
+                               uint8_t *d_pixels, size_t pixel_stride);
+
 // ---- encode -------------------------------------------------------------------------
 // a13: Rectangular.pack
 hipError_t launch_pack(hipStream_t stream, const uint8_t *d_pixels, size_t npixels,

@@ -1,0 +1,500 @@
+// kernels_fused.hip -- fused Spectral -> pixels fast path for the built-in 8-bit formats.
+//
+// Replaces idct() -> interleaved(cosite: false) -> unpack(as:) (decode.swift:4154, 4182,
+// 4294) for ycc8 images whose luma has the full sampling factor and whose chroma planes are
+// subsampled 1x or 2x per axis (4:4:4, 4:2:2, 4:4:0, 4:2:0), and for y8 images, without
+// materialising Planar / Rectangular in HBM.  Two launches:
+//
+//   k_chroma_idct   Cb and Cr: dequantise + IDCT, clamp, store as uint8 planes (a scratch of
+//                   0.5 B/px for 4:2:0 -- small enough to stay in L2 / Infinity Cache).
+//   k_luma_fused    one luma 8x8 block per work-item: dequantise + IDCT in registers; the
+//                   workgroup stages its chroma tile (+1 sample halo, clamped to the padded
+//                   plane like decode.swift:4245-4246) in LDS; bilinear upsample, YCbCr->RGB,
+//                   pack and store 8 rows x 24 B.
+//
+// Exactness of the upsample shortcut.  For centred 2x upsampling the reference's weights are
+// t in {1/4, 3/4} (decode.swift:4231-4251), so u00*(1-t) + u01*t etc. are sums of small
+// integers times binary fractions: every intermediate is exactly representable in binary32
+// (<= 12 significant bits).  (3a + b) / 4 evaluated with an FMA is therefore the SAME value,
+// and round-half-away of an exact multiple of 1/16 is floor(v + 0.5).  The index clamp
+// max(i, 0) at the left/top edge reproduces the reference's t = 0 case (decode.swift:4240,
+// 4250) because 0.25*c + 0.75*c == c exactly.  Everything that rounds (dequantise, IDCT,
+// colour matrix) is evaluated op-for-op as in dct.hpp / the reference.
+#pragma clang fp contract(off)
+
+#include "dct.hpp"
+#include "kernels.hpp"
+
+namespace jpeg_amd {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int TBX = 32;  // luma blocks per tile row   (tile = 256 x 64 px)
+constexpr int TBY = 8;   // luma blocks per tile column
+
+// ---------------------------------------------------------------------------------------
+// K1: chroma planes -> uint8 samples.  blockIdx.z selects the plane (same geometry).
+// ---------------------------------------------------------------------------------------
+struct ChromaArgs {
+    const int16_t *coef[2];
+    size_t coef_stride[2];
+    uint8_t *out[2];
+    size_t out_stride;
+    const uint16_t *quanta;
+    size_t quanta_stride;
+    int qi[2];
+    int ux, nblocks;
+};
+
+__global__ __launch_bounds__(kThreads) void k_chroma_idct(ChromaArgs a)
+{
+    __shared__ float sq[64];
+    const int img = blockIdx.y, pl = blockIdx.z;
+    if (threadIdx.x < 64) {
+        const int k = threadIdx.x & 7, h = threadIdx.x >> 3;
+        sq[threadIdx.x] = modulate_entry(k, h, 0.125f,
+                                         a.quanta[img * a.quanta_stride + 64 * a.qi[pl] + zigzag_of(k, h)]);
+    }
+    __syncthreads();
+    const int b = blockIdx.x * kThreads + threadIdx.x;
+    if (b >= a.nblocks) return;
+    const int by = b / a.ux, bx = b - by * a.ux;
+
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.coef[pl] + img * a.coef_stride[pl] + (size_t)64 * b);
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 v = src[i];
+        w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    float g[64];
+    idct_block(w, sq, 128.5f, g);  // level = 2^(P-1) + 0.5, P = 8
+
+    const size_t pitch = (size_t)8 * a.ux;
+    uint8_t *dst = a.out[pl] + img * a.out_stride + (size_t)8 * by * pitch + 8 * bx;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        // clamp [0, 255] + truncate == saturating convert of floor(v)
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            lo = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + x]), x, lo);
+            hi = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 + x]), x, hi);
+        }
+        *reinterpret_cast<uint2 *>(dst + y * pitch) = make_uint2(lo, hi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: luma IDCT + chroma upsample + colour + store
+// ---------------------------------------------------------------------------------------
+struct LumaArgs {
+    const int16_t *coef;
+    size_t coef_stride;
+    const uint8_t *cb, *cr;  // uint8 planes [ph_c][pw_c] (unused for grey)
+    size_t c_stride;
+    const uint16_t *quanta;
+    size_t quanta_stride;
+    int qi;
+    int ux, uy;              // luma units
+    int pw_c, ph_c;          // padded chroma plane size
+    int W, H;
+    uint8_t *out;
+    size_t out_stride;
+    int tiles_x, tiles_per_image, total_tiles;
+};
+
+template <int N>
+__device__ __forceinline__ float ubyte(uint32_t v)
+{
+    return (float)((v >> (8 * N)) & 0xffu);  // v_cvt_f32_ubyteN
+}
+
+// 3a + b, exact (small integers): one v_fma_f32
+__device__ __forceinline__ float w31(float a, float b) { return __builtin_fmaf(a, 3.0f, b); }
+
+// one row of 2x-upsampled weights from 6 neighbours p[0..5] (p[0] = sample left of the
+// block's first chroma sample): out[x] = 4 * bilinear value
+__device__ __forceinline__ void lerp_row_2x(const float (&p)[6], float (&o)[8])
+{
+    o[0] = w31(p[1], p[0]); o[1] = w31(p[1], p[2]);
+    o[2] = w31(p[2], p[1]); o[3] = w31(p[2], p[3]);
+    o[4] = w31(p[3], p[2]); o[5] = w31(p[3], p[4]);
+    o[6] = w31(p[4], p[3]); o[7] = w31(p[4], p[5]);
+}
+
+// SX, SY: chroma subsampling per axis (1 or 2); MODE: 0 = YCbCr bytes, 1 = RGB bytes;
+// CHROMA = false: single-plane (grey) image.
+// FAST: W % 16 == 0 and 16-byte aligned rows, so every 16-byte chunk of a row segment is either
+// entirely inside the image or entirely outside (no byte-wise tail code in the hot path).
+//
+// Persistent, fully independent WAVES.  The unit of work is a strip of 32 x 2 luma blocks
+// (256 x 16 px); wave g of the launch walks strips g, g + nwaves, ...  Lanes 0..31 are 32
+// consecutive blocks of the strip's first block row, lanes 32..63 the same columns of the
+// second.  Everything a wave touches in LDS is private to it: there is no workgroup barrier,
+// waves drift apart and their memory and arithmetic phases interleave on the SIMD.
+//
+// What bounds this kernel is how many waves are READY to issue, not HBM: one wave alone issues
+// a VALU instruction only every ~7 cycles, three ready waves saturate the SIMD
+// (tools/probe_mix.hip).  So the design keeps waves from parking:
+//   - the 8 KiB of coefficients of the NEXT strip are fetched by LDS-DMA
+//     (global_load_lds_dwordx4) into the wave's LDS buffer while it works on the current one;
+//     no VGPRs are spent on the prefetch.  The LDS image is lane-linear (a DMA requirement);
+//     an XOR swizzle on the global SOURCE address makes the later per-work-item ds_read_b128
+//     (stride 128 B) bank-conflict-free;
+//   - the chroma samples under the strip are requested before IDCT pass 1 and land during it;
+//   - no register spills (a spill reload waits with vmcnt(0) and thereby for every store in
+//     flight): the 64 luma samples are packed into 16 VGPRs after the IDCT, phases are kept
+//     apart with scheduling barriers, strip geometry lives in SGPRs.
+// Pixels leave through an LDS staging row so that every global store instruction writes whole
+// 16-byte chunks of contiguous 768-byte row segments.
+using lds_void = __attribute__((address_space(3))) void;
+using gbl_void = const __attribute__((address_space(1))) void;
+
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST>
+__global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
+{
+    constexpr int NW = kThreads / 64;                    // waves per workgroup
+    constexpr int CW = TBX * 8 / SX;                     // chroma samples per strip row
+    constexpr int CR = 2 * 8 / SY;                       // chroma rows under a strip (2 block rows)
+    constexpr int HX = SX == 2 ? 4 : 0;                  // halo bytes per side (keeps dword alignment)
+    constexpr int HY = SY == 2 ? 1 : 0;
+    constexpr int PITCH = (CW + 2 * HX) / 4;             // dwords per LDS row
+    constexpr int ROWS = CR + 2 * HY;
+    constexpr int PLANE = CHROMA ? ROWS * PITCH : 1;
+    constexpr int NF = CHROMA ? (2 * PLANE + 63) / 64 : 1;  // fill dwords per lane
+    constexpr int SEG_DW = TBX * 6;                      // one 32-block row segment: 768 B
+    __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
+    __shared__ __attribute__((aligned(16))) uint32_t stage[NW][2 * SEG_DW]; // one pixel row x 2 block rows
+    __shared__ uint32_t scw[NW][2 * PLANE];              // chroma samples under the strip (+ halo)
+    __shared__ float sqw[NW][64];                        // modulated table
+
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // strip math stays scalar
+    uint32_t *stage_w = stage[wave];
+    uint32_t *coef_w = coefbuf[wave];
+    uint32_t *sc = scw[wave];
+    float *sq = sqw[wave];
+
+    // strip s -> image, strip row (2 block rows), strip column (32 blocks)
+    auto locate = [&](int s, int &img, int &syi, int &sxi) {
+        img = s / a.tiles_per_image;
+        const int rem = s - img * a.tiles_per_image;
+        syi = rem / a.tiles_x;
+        sxi = rem - syi * a.tiles_x;
+    };
+
+    // LDS-DMA of the 64 blocks of strip s: instruction i moves 64 x 16 B; slot
+    // u = 64 i + lane holds chunk (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3.
+    auto dma_strip = [&](int s, int lane) {
+        int img, syi, sxi;
+        locate(s, img, syi, sxi);
+        const int16_t *base = a.coef + img * a.coef_stride;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = 8 * i + (lane >> 3);  // block within the strip: column b & 31, row b >> 5
+            const int bx = sxi * TBX + (b & 31), by = 2 * syi + (b >> 5);
+            // blocks outside the plane fetch block 0; the store predicate discards their pixels
+            const uint32_t blk = (bx < a.ux && by < a.uy) ? (uint32_t)by * a.ux + bx : 0u;
+            const int c = (lane & 7) ^ ((b >> 1) & 7);
+            const char *g = reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c);
+            __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(coef_w + 256 * i), 16, 0, 0);
+        }
+    };
+
+    const int nwaves = gridDim.x * NW;
+    int s = blockIdx.x * NW + wave;
+    if (s >= a.total_tiles) return;
+    dma_strip(s, lane0);
+    int img_of_table = -1;
+
+    for (; s < a.total_tiles; s += nwaves) {
+        // Launder the lane id once per strip: everything below that depends only on the lane is
+        // cheap to recompute, but hoisted out of this loop it would pin ~60 VGPRs for good.
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int lbx = lane & (TBX - 1), seg = lane >> 5;
+        int img, syi, sxi;
+        locate(s, img, syi, sxi);
+
+        // ---- modulated table (only when the image changes) ----
+        if (img != img_of_table) {
+            const int qk = lane & 7, qh = lane >> 3;
+            sq[lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi + zigzag_of(qk, qh)]);
+            img_of_table = img;
+        }
+
+        // ---- this strip's coefficients: wait for the DMA, read 8 x 16 B (swizzled) ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[32];
+        {
+            const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
+            const int sw = (lane >> 1) & 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 v = cw[i ^ sw];
+                w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+        }
+
+        // ---- chroma samples under the strip (+ halo) -> registers; they land during the IDCT ----
+        uint32_t cf[NF];
+        if constexpr (CHROMA) {
+            const int cx0 = sxi * CW, cy0 = syi * CR;
+            const int pwd = a.pw_c >> 2;
+            const int frow0 = lane / PITCH, fcol0 = lane - frow0 * PITCH;
+            int row = frow0, col = fcol0;  // row runs over both planes
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                cf[n] = 0;
+                if (n * 64 + lane < 2 * PLANE) {
+                    const int pl = row >= ROWS ? 1 : 0;
+                    const int gy = min(max(cy0 - HY + row - pl * ROWS, 0), a.ph_c - 1);
+                    const int gd = (cx0 - HX) / 4 + col;
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>((pl ? a.cr : a.cb) + img * a.c_stride);
+                    uint32_t v = src[(uint32_t)(gy * (a.pw_c >> 2)) + (uint32_t)min(max(gd, 0), pwd - 1)];
+                    if (gd < 0) v = (v & 0xffu) * 0x01010101u;        // replicate the first sample
+                    else if (gd >= pwd) v = (v >> 24) * 0x01010101u;   // replicate the last sample
+                    cf[n] = v;
+                }
+                col += 64 % PITCH; row += 64 / PITCH;
+                if (col >= PITCH) { col -= PITCH; ++row; }
+            }
+        }
+
+        // ---- luma: dequantise + IDCT; clamp + truncate == saturating convert of floor(v) ----
+        uint32_t ypk[16];  // ypk[2*y + h]: samples 4h..4h+3 of row y
+        {
+            float g[64];
+            idct_block(w, sq, 128.5f, g);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                uint32_t p = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) p = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[4 * i + x]), x, p);
+                ypk[i] = p;
+            }
+        }
+
+        // ---- the coefficient buffer is consumed: prefetch the next strip into it ----
+        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane);
+
+        // ---- publish the chroma samples to this wave's LDS tile ----
+        if constexpr (CHROMA) {
+#pragma unroll
+            for (int n = 0; n < NF; ++n)
+                if (n * 64 + lane < 2 * PLANE) sc[n * 64 + lane] = cf[n];
+        }
+        // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- chroma rows, produced just in time from the LDS tile ----
+        constexpr float inv = 1.0f / (float)((SX == 2 ? 4 : 1) * (SY == 2 ? 4 : 1));
+        constexpr float bias = MODE == 1 ? -127.5f : 0.5f;
+        // horizontally interpolated chroma row j of this block's patch (x4 when SX == 2)
+        auto hrow = [&](int pl, int j, float (&o)[8]) {
+            const uint32_t *row = sc + pl * PLANE + (seg * (8 / SY) + j) * PITCH;
+            if constexpr (SX == 2) {
+                const uint32_t d0 = row[lbx], d1 = row[lbx + 1], d2 = row[lbx + 2];
+                const float p[6] = {ubyte<3>(d0), ubyte<0>(d1), ubyte<1>(d1),
+                                    ubyte<2>(d1), ubyte<3>(d1), ubyte<0>(d2)};
+                lerp_row_2x(p, o);
+            } else {
+                const uint32_t d0 = row[2 * lbx], d1 = row[2 * lbx + 1];
+                o[0] = ubyte<0>(d0); o[1] = ubyte<1>(d0); o[2] = ubyte<2>(d0); o[3] = ubyte<3>(d0);
+                o[4] = ubyte<0>(d1); o[5] = ubyte<1>(d1); o[6] = ubyte<2>(d1); o[7] = ubyte<3>(d1);
+            }
+        };
+        // final chroma value of one pixel from the vertically combined sum v
+        auto finish = [&](float v) -> float {
+            if constexpr (SX == 1 && SY == 1) return MODE == 1 ? v - 128.0f : v;
+            else return floorf(__builtin_fmaf(v, inv, bias));
+        };
+
+        float hw[2][3][8];  // SY == 2: patch rows j-1, j, j+1 of both planes (sliding window)
+        if constexpr (CHROMA && SY == 2) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) { hrow(pl, 0, hw[pl][0]); hrow(pl, 1, hw[pl][1]); }
+        }
+
+        // ---- store geometry: per pixel row the strip's 2 segments are 96 chunks of 16 B ----
+        const int tile_px = min(TBX * 8, a.W - TBX * 8 * sxi);  // pixels of this strip inside the image
+        const int nb = 3 * tile_px;                              // bytes per row segment to write
+        uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(16 * syi) * a.W + TBX * 8 * sxi) * 3;
+        const uint32_t pitch = 3u * a.W;
+
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {  // pixel row y of both block rows
+            if ((y & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+            float cv[2][8];
+            if constexpr (CHROMA) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    if constexpr (SY == 2) {
+                        // window holds patch rows (y>>1), (y>>1)+1, (y>>1)+2; the nearer row
+                        // (middle) weighs 3, the farther one (above for even y, below for odd) 1
+                        if ((y & 1) == 1) hrow(pl, (y >> 1) + 2, hw[pl][2]);
+#pragma unroll
+                        for (int x = 0; x < 8; ++x)
+                            cv[pl][x] = finish(w31(hw[pl][1][x], hw[pl][(y & 1) ? 2 : 0][x]));
+                        if ((y & 1) == 1) {
+#pragma unroll
+                            for (int x = 0; x < 8; ++x) { hw[pl][0][x] = hw[pl][1][x]; hw[pl][1][x] = hw[pl][2][x]; }
+                        }
+                    } else {
+                        float h[8];
+                        hrow(pl, y, h);
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) cv[pl][x] = finish(h[x]);
+                    }
+                }
+            }
+            uint32_t d[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const uint32_t yw = ypk[2 * y + (x >> 2)];
+                const float yy = (x & 3) == 0 ? ubyte<0>(yw) : (x & 3) == 1 ? ubyte<1>(yw)
+                                 : (x & 3) == 2 ? ubyte<2>(yw) : ubyte<3>(yw);
+                float c0, c1, c2;
+                if constexpr (MODE == 1) {
+                    if constexpr (CHROMA) {
+                        const float pb = cv[0][x], pr = cv[1][x];
+                        // jpeg.swift:441-453, op for op (the 0.0 * c terms are exact no-ops)
+                        c0 = floorf(yy + 1.40200f * pr);
+                        c1 = floorf((yy + -0.34414f * pb) + -0.71414f * pr);
+                        c2 = floorf(yy + 1.77200f * pb);
+                    } else {
+                        c0 = c1 = c2 = yy;  // cb = cr = 128: every matrix term is +-0
+                    }
+                } else {
+                    c0 = yy;
+                    c1 = CHROMA ? cv[0][x] : 128.0f;
+                    c2 = CHROMA ? cv[1][x] : 128.0f;
+                }
+                // saturating convert of an integer-valued float == clamp [0, 255] + truncate
+                d[(3 * x + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c0, (3 * x + 0) & 3, d[(3 * x + 0) >> 2]);
+                d[(3 * x + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c1, (3 * x + 1) & 3, d[(3 * x + 1) >> 2]);
+                d[(3 * x + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c2, (3 * x + 2) & 3, d[(3 * x + 2) >> 2]);
+            }
+            // stage the row (LDS ops of one wave execute in order), then store 16-byte chunks
+            uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
+            sw[0] = make_uint2(d[0], d[1]);
+            sw[1] = make_uint2(d[2], d[3]);
+            sw[2] = make_uint2(d[4], d[5]);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                if (it == 0 || lane < 32) {
+                    const int c = it * 64 + lane;          // chunk of 16 B among 2 segments x 48
+                    const int sg = c >= 48 ? 1 : 0, j = c - 48 * sg;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(stage_w + 4 * c);
+                    const int grow = 16 * syi + 8 * sg + y;
+                    if (grow < a.H && 16 * j < nb) {
+                        uint8_t *o = strip_out + ((uint32_t)(8 * sg + y) * pitch + 16u * j);
+                        if constexpr (FAST) {
+                            *reinterpret_cast<uint4 *>(o) = v;
+                        } else {
+                            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+                            for (int k = 0; k < 16; ++k)
+                                if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
+
+template <int MODE, bool FAST>
+hipError_t launch_luma(hipStream_t stream, dim3 grid, const LumaArgs &a, int sx, int sy, bool chroma)
+{
+#define JA_K(SX_, SY_, CH_) hipLaunchKernelGGL((k_luma_fused<SX_, SY_, MODE, CH_, FAST>), grid, dim3(kThreads), 0, stream, a)
+    if (!chroma) JA_K(1, 1, false);
+    else if (sx == 2 && sy == 2) JA_K(2, 2, true);
+    else if (sx == 2 && sy == 1) JA_K(2, 1, true);
+    else if (sx == 1 && sy == 2) JA_K(1, 2, true);
+    else JA_K(1, 1, true);
+#undef JA_K
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool fused_decode_supported(const jpeg_amd_layout &L, bool cosited)
+{
+    if (L.precision != 8) return false;
+    auto units = [](int size, int stride) { return size / stride + (size % stride != 0 ? 1 : 0); };
+    for (int p = 0; p < L.nplanes; ++p) {  // geometry must be the layout-derived one
+        if (L.units_x[p] != units(L.width * L.factor_x[p], 8 * L.scale_x)) return false;
+        if (L.units_y[p] != units(L.height * L.factor_y[p], 8 * L.scale_y)) return false;
+    }
+    if (L.nplanes == 1) return true;  // single plane: crop copy whatever the factor (decode.swift:4185)
+    if (L.nplanes != 3 || cosited) return false;
+    if (L.factor_x[0] != L.scale_x || L.factor_y[0] != L.scale_y) return false;
+    if (L.scale_x > 2 || L.scale_y > 2) return false;
+    for (int p = 1; p < 3; ++p)
+        if (L.factor_x[p] != 1 || L.factor_y[p] != 1) return false;
+    return true;
+}
+
+size_t fused_decode_scratch_bytes(const jpeg_amd_layout &L, int n_images)
+{
+    if (L.nplanes == 1) return 0;
+    const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
+    return 2 * ((plane * n_images + 255) & ~(size_t)255);
+}
+
+hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L,
+                               const PlaneSet &coef, QuantaRef q, bool rgb, void *scratch,
+                               uint8_t *d_pixels, size_t pixel_stride)
+{
+    const bool chroma = L.nplanes == 3;
+    LumaArgs la{};
+    if (chroma) {
+        const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
+        const size_t half = (plane * n_images + 255) & ~(size_t)255;
+        ChromaArgs ca{};
+        for (int i = 0; i < 2; ++i) {
+            ca.coef[i] = static_cast<const int16_t *>(coef.ptr[1 + i]);
+            ca.coef_stride[i] = coef.stride[1 + i];
+            ca.out[i] = static_cast<uint8_t *>(scratch) + i * half;
+            ca.qi[i] = L.qi[1 + i];
+        }
+        ca.out_stride = plane;
+        ca.quanta = q.d_quanta; ca.quanta_stride = q.image_stride;
+        ca.ux = L.units_x[1]; ca.nblocks = L.units_x[1] * L.units_y[1];
+        if (ca.nblocks > 0) {
+            hipLaunchKernelGGL(k_chroma_idct, dim3(blocks_for(ca.nblocks), n_images, 2), dim3(kThreads), 0, stream, ca);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        la.cb = ca.out[0]; la.cr = ca.out[1]; la.c_stride = plane;
+        la.pw_c = 8 * L.units_x[1]; la.ph_c = 8 * L.units_y[1];
+    }
+    la.coef = static_cast<const int16_t *>(coef.ptr[0]);
+    la.coef_stride = coef.stride[0];
+    la.quanta = q.d_quanta; la.quanta_stride = q.image_stride; la.qi = L.qi[0];
+    la.ux = L.units_x[0]; la.uy = L.units_y[0];
+    la.W = L.width; la.H = L.height;
+    la.out = d_pixels; la.out_stride = pixel_stride;
+    // unit of work: strip of 32 x 2 luma blocks; persistent waves, 3 per SIMD (VGPR- and LDS-bound)
+    la.tiles_x = (la.ux + TBX - 1) / TBX;
+    const int strips_y = (la.uy + 1) / 2;
+    la.tiles_per_image = la.tiles_x * strips_y;
+    la.total_tiles = la.tiles_per_image * n_images;
+    if (la.total_tiles == 0) return hipSuccess;
+    const int wgs = (la.total_tiles + 3) / 4;
+    const dim3 grid(wgs < 768 ? wgs : 768);
+    const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;
+    const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
+    if (fast)
+        return rgb ? launch_luma<1, true>(stream, grid, la, sx, sy, chroma)
+                   : launch_luma<0, true>(stream, grid, la, sx, sy, chroma);
+    return rgb ? launch_luma<1, false>(stream, grid, la, sx, sy, chroma)
+               : launch_luma<0, false>(stream, grid, la, sx, sy, chroma);
+}
+
+}  // namespace jpeg_amd

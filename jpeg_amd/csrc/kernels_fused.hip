@@ -149,8 +149,17 @@ __device__ __forceinline__ void lerp_row_2x(const float (&p)[6], float (&o)[8])
 //     apart with scheduling barriers, strip geometry lives in SGPRs.
 // Pixels leave through an LDS staging row so that every global store instruction writes whole
 // 16-byte chunks of contiguous 768-byte row segments.
-using lds_void = __attribute__((address_space(3))) void;
-using gbl_void = const __attribute__((address_space(1))) void;
+// One 16-byte-per-lane LDS-DMA: lane l's 16 B at `g` land at LDS byte address lds + 16 l.
+// Issued from inline asm on purpose: hipcc cannot tell which LDS array a DMA targets, so
+// after a __builtin_amdgcn_global_load_lds it makes the NEXT LDS read of any array wait with
+// vmcnt(0) -- i.e. for the prefetch it was supposed to overlap.  Hidden from the compiler, the
+// DMA is only waited for by the explicit s_waitcnt at the top of the next strip.  (Extra
+// outstanding VM operations can only make the compiler's own counted waits longer, never
+// shorter, because loads retire in order.)
+__device__ __forceinline__ void lds_dma16(const void *g, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory");
+}
 
 template <int SX, int SY, int MODE, bool CHROMA, bool FAST>
 __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
@@ -174,6 +183,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // strip math stays scalar
     uint32_t *stage_w = stage[wave];
     uint32_t *coef_w = coefbuf[wave];
+    // LDS byte address of the wave's coefficient buffer (low 32 bits of the flat shared address)
+    const uint32_t coef_lds = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)coef_w);
     uint32_t *sc = scw[wave];
     float *sq = sqw[wave];
 
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             const uint32_t blk = (bx < a.ux && by < a.uy) ? (uint32_t)by * a.ux + bx : 0u;
             const int c = (lane & 7) ^ ((b >> 1) & 7);
             const char *g = reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c);
-            __builtin_amdgcn_global_load_lds((gbl_void *)g, (lds_void *)(coef_w + 256 * i), 16, 0, 0);
+            lds_dma16(g, coef_lds + 1024 * i);
         }
     };
 
@@ -238,26 +250,24 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             }
         }
 
-        // ---- chroma samples under the strip (+ halo) -> registers; they land during the IDCT ----
+        // ---- chroma samples under the strip (+ halo) -> registers; they land during the IDCT.
+        //      Branch-free and back to back: a conditional around a load makes the compiler wait
+        //      for each one separately (11 serialized HBM latencies per strip).  Row / column
+        //      indices are clamped to the padded plane; the edge replication of a clamped COLUMN
+        //      is patched in when the samples are published (edge strips only). ----
         uint32_t cf[NF];
+        const int cx0 = sxi * CW, cy0 = syi * CR;
+        const int pwd = a.pw_c >> 2;
+        const int frow0 = lane / PITCH, fcol0 = lane - frow0 * PITCH;
         if constexpr (CHROMA) {
-            const int cx0 = sxi * CW, cy0 = syi * CR;
-            const int pwd = a.pw_c >> 2;
-            const int frow0 = lane / PITCH, fcol0 = lane - frow0 * PITCH;
             int row = frow0, col = fcol0;  // row runs over both planes
 #pragma unroll
             for (int n = 0; n < NF; ++n) {
-                cf[n] = 0;
-                if (n * 64 + lane < 2 * PLANE) {
-                    const int pl = row >= ROWS ? 1 : 0;
-                    const int gy = min(max(cy0 - HY + row - pl * ROWS, 0), a.ph_c - 1);
-                    const int gd = (cx0 - HX) / 4 + col;
-                    const uint32_t *src = reinterpret_cast<const uint32_t *>((pl ? a.cr : a.cb) + img * a.c_stride);
-                    uint32_t v = src[(uint32_t)(gy * (a.pw_c >> 2)) + (uint32_t)min(max(gd, 0), pwd - 1)];
-                    if (gd < 0) v = (v & 0xffu) * 0x01010101u;        // replicate the first sample
-                    else if (gd >= pwd) v = (v >> 24) * 0x01010101u;   // replicate the last sample
-                    cf[n] = v;
-                }
+                const int pl = row >= ROWS ? 1 : 0;
+                const int gy = min(max(cy0 - HY + row - pl * ROWS, 0), a.ph_c - 1);
+                const int gd = min(max((cx0 - HX) / 4 + col, 0), pwd - 1);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>((pl && row < 2 * ROWS ? a.cr : a.cb) + img * a.c_stride);
+                cf[n] = src[(uint32_t)(gy * pwd + gd)];   // lanes past the tile re-read a valid sample
                 col += 64 % PITCH; row += 64 / PITCH;
                 if (col >= PITCH) { col -= PITCH; ++row; }
             }
@@ -277,15 +287,35 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             }
         }
 
-        // ---- the coefficient buffer is consumed: prefetch the next strip into it ----
-        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane);
+        // Pin the IDCT HERE: LLVM otherwise sinks it below the publish / DMA (its results are
+        // first used in the colour phase), and the wave would park on the chroma loads before
+        // doing any arithmetic instead of letting them land during the IDCT.
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(ypk[i]));
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- publish the chroma samples to this wave's LDS tile ----
         if constexpr (CHROMA) {
+            const bool edge = (HX > 0 && sxi == 0) || (cx0 - HX) / 4 + PITCH > pwd;  // wave-uniform
+            if (edge) {
+                // a clamped column must replicate the plane's first / last SAMPLE, not its dword
+                int col = fcol0;
+#pragma unroll
+                for (int n = 0; n < NF; ++n) {
+                    const int gd = (cx0 - HX) / 4 + col;
+                    const uint32_t v = cf[n];
+                    cf[n] = gd < 0 ? (v & 0xffu) * 0x01010101u : gd >= pwd ? (v >> 24) * 0x01010101u : v;
+                    col += 64 % PITCH;
+                    if (col >= PITCH) col -= PITCH;
+                }
+            }
 #pragma unroll
             for (int n = 0; n < NF; ++n)
-                if (n * 64 + lane < 2 * PLANE) sc[n * 64 + lane] = cf[n];
+                if (n < NF - 1 || n * 64 + lane < 2 * PLANE) sc[n * 64 + lane] = cf[n];
         }
+        // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
+        //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
+        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane);
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
 

@@ -160,6 +160,16 @@ __device__ __forceinline__ void lds_dma16(const void *g, uint32_t lds)
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory");
 }
+// Same with a scalar 64-bit base + per-lane 32-bit byte offset (no vector address arithmetic).
+__device__ __forceinline__ void lds_dma16_s(uint64_t sbase, uint32_t voff, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
+// 4 bytes per lane: lane l's dword lands at LDS byte address lds + 4 l.
+__device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
 
 template <int SX, int SY, int MODE, bool CHROMA, bool FAST>
 __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
@@ -187,6 +197,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     const uint32_t coef_lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)coef_w);
     uint32_t *sc = scw[wave];
+    const uint32_t sc_lds = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sc);
     float *sq = sqw[wave];
 
     // strip s -> image, strip row (2 block rows), strip column (32 blocks)
@@ -203,6 +215,19 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         int img, syi, sxi;
         locate(s, img, syi, sxi);
         const int16_t *base = a.coef + img * a.coef_stride;
+        if (sxi * TBX + TBX <= a.ux && 2 * syi + 2 <= a.uy) {
+            // interior strip (wave-uniform test): the block index is scalar, only the lane's
+            // place inside an 8-block group (and its swizzled chunk) is per lane
+            const uint32_t l3 = lane >> 3;
+            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);  // even i; odd i: chunk ^ 4
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t blk0 = (uint32_t)(2 * syi + (i >> 2)) * a.ux + sxi * TBX + 8 * (i & 3);
+                const uint64_t sb = reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7);
+                lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int b = 8 * i + (lane >> 3);  // block within the strip: column b & 31, row b >> 5
@@ -250,26 +275,23 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             }
         }
 
-        // ---- chroma samples under the strip (+ halo) -> registers; they land during the IDCT.
-        //      Branch-free and back to back: a conditional around a load makes the compiler wait
-        //      for each one separately (11 serialized HBM latencies per strip).  Row / column
-        //      indices are clamped to the padded plane; the edge replication of a clamped COLUMN
-        //      is patched in when the samples are published (edge strips only). ----
-        uint32_t cf[NF];
+        // ---- chroma samples under the strip (+ halo): one LDS-DMA per row straight into this
+        //      wave's LDS tile (lane = dword column); they land during the IDCT.  Row index
+        //      clamped by the scalar unit, column index clamped per lane to the padded plane;
+        //      the replication a clamped COLUMN needs is patched in LDS on edge strips only. ----
         const int cx0 = sxi * CW, cy0 = syi * CR;
         const int pwd = a.pw_c >> 2;
-        const int frow0 = lane / PITCH, fcol0 = lane - frow0 * PITCH;
         if constexpr (CHROMA) {
-            int row = frow0, col = fcol0;  // row runs over both planes
+            const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + lane, 0), pwd - 1);
+            if (lane < PITCH) {
 #pragma unroll
-            for (int n = 0; n < NF; ++n) {
-                const int pl = row >= ROWS ? 1 : 0;
-                const int gy = min(max(cy0 - HY + row - pl * ROWS, 0), a.ph_c - 1);
-                const int gd = min(max((cx0 - HX) / 4 + col, 0), pwd - 1);
-                const uint32_t *src = reinterpret_cast<const uint32_t *>((pl && row < 2 * ROWS ? a.cr : a.cb) + img * a.c_stride);
-                cf[n] = src[(uint32_t)(gy * pwd + gd)];   // lanes past the tile re-read a valid sample
-                col += 64 % PITCH; row += 64 / PITCH;
-                if (col >= PITCH) { col -= PITCH; ++row; }
+                for (int vr = 0; vr < 2 * ROWS; ++vr) {
+                    const int pl = vr >= ROWS ? 1 : 0;
+                    const int gy = min(max(cy0 - HY + vr - pl * ROWS, 0), a.ph_c - 1);
+                    const uint64_t rowbase = reinterpret_cast<uint64_t>((pl ? a.cr : a.cb) + img * a.c_stride) +
+                                             (uint64_t)((uint32_t)gy * (uint32_t)a.pw_c);
+                    lds_dma4_s(rowbase, coff, sc_lds + 4 * PITCH * vr);
+                }
             }
         }
 
@@ -287,31 +309,25 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             }
         }
 
-        // Pin the IDCT HERE: LLVM otherwise sinks it below the publish / DMA (its results are
-        // first used in the colour phase), and the wave would park on the chroma loads before
-        // doing any arithmetic instead of letting them land during the IDCT.
+        // Pin the IDCT HERE: LLVM otherwise sinks it below the waits / DMA (its results are first
+        // used in the colour phase) and the wave would park on the chroma rows before doing any
+        // arithmetic instead of letting them land during the IDCT.
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(ypk[i]));
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- publish the chroma samples to this wave's LDS tile ----
+        // ---- the chroma rows have landed (they are the only VM operations in flight) ----
         if constexpr (CHROMA) {
-            const bool edge = (HX > 0 && sxi == 0) || (cx0 - HX) / 4 + PITCH > pwd;  // wave-uniform
-            if (edge) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int first_bad = pwd - (cx0 - HX) / 4;          // first column past the plane
+            if ((HX > 0 && sxi == 0) || first_bad < PITCH) {     // wave-uniform: edge strips only
                 // a clamped column must replicate the plane's first / last SAMPLE, not its dword
-                int col = fcol0;
-#pragma unroll
-                for (int n = 0; n < NF; ++n) {
-                    const int gd = (cx0 - HX) / 4 + col;
-                    const uint32_t v = cf[n];
-                    cf[n] = gd < 0 ? (v & 0xffu) * 0x01010101u : gd >= pwd ? (v >> 24) * 0x01010101u : v;
-                    col += 64 % PITCH;
-                    if (col >= PITCH) col -= PITCH;
+                if (lane < 2 * ROWS) {
+                    uint32_t *row = sc + lane * PITCH;
+                    if (HX > 0 && sxi == 0) row[0] = (row[0] & 0xffu) * 0x01010101u;
+                    for (int c = max(first_bad, 0); c < PITCH; ++c) row[c] = (row[c] >> 24) * 0x01010101u;
                 }
             }
-#pragma unroll
-            for (int n = 0; n < NF; ++n)
-                if (n < NF - 1 || n * 64 + lane < 2 * PLANE) sc[n * 64 + lane] = cf[n];
         }
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
@@ -348,11 +364,17 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             for (int pl = 0; pl < 2; ++pl) { hrow(pl, 0, hw[pl][0]); hrow(pl, 1, hw[pl][1]); }
         }
 
-        // ---- store geometry: per pixel row the strip's 2 segments are 96 chunks of 16 B ----
+        // ---- store geometry: per pixel row the strip's 2 segments are 96 chunks of 16 B; a lane
+        //      stores chunk `lane` (and lanes 0..31 also chunk 64 + lane).  Byte offsets relative to
+        //      the strip's first pixel are computed once; the row advance is scalar. ----
         const int tile_px = min(TBX * 8, a.W - TBX * 8 * sxi);  // pixels of this strip inside the image
         const int nb = 3 * tile_px;                              // bytes per row segment to write
-        uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(16 * syi) * a.W + TBX * 8 * sxi) * 3;
         const uint32_t pitch = 3u * a.W;
+        uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(16 * syi) * a.W + TBX * 8 * sxi) * 3;
+        const int sg0 = lane >= 48 ? 1 : 0, j0 = lane - 48 * sg0, j1 = 16 + lane;
+        const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = 8u * pitch + 16u * j1;
+        const bool full = 16 * syi + 16 <= a.H && tile_px == TBX * 8;   // wave-uniform
+        const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
 
 #pragma unroll
         for (int y = 0; y < 8; ++y) {  // pixel row y of both block rows
@@ -412,23 +434,25 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             sw[0] = make_uint2(d[0], d[1]);
             sw[1] = make_uint2(d[2], d[3]);
             sw[2] = make_uint2(d[4], d[5]);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                if (it == 0 || lane < 32) {
-                    const int c = it * 64 + lane;          // chunk of 16 B among 2 segments x 48
-                    const int sg = c >= 48 ? 1 : 0, j = c - 48 * sg;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(stage_w + 4 * c);
-                    const int grow = 16 * syi + 8 * sg + y;
-                    if (grow < a.H && 16 * j < nb) {
-                        uint8_t *o = strip_out + ((uint32_t)(8 * sg + y) * pitch + 16u * j);
-                        if constexpr (FAST) {
-                            *reinterpret_cast<uint4 *>(o) = v;
-                        } else {
-                            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-                            for (int k = 0; k < 16; ++k)
-                                if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
-                        }
+            {
+                uint8_t *rowp = strip_out + (size_t)y * pitch;   // scalar
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(stage_w + 4 * lane);
+                const uint4 v1 = *reinterpret_cast<const uint4 *>(stage_w + 4 * (64 + (lane & 31)));
+                auto put = [&](uint8_t *o, const uint4 &v, int j) {
+                    if constexpr (FAST) {
+                        *reinterpret_cast<uint4 *>(o) = v;
+                    } else {
+                        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+                        for (int k = 0; k < 16; ++k)
+                            if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
                     }
+                };
+                if (FAST && full) {
+                    put(rowp + voff0, v0, j0);
+                    if (lane < 32) put(rowp + voff1, v1, j1);
+                } else {
+                    if (col0 && 16 * syi + 8 * sg0 + y < a.H) put(rowp + voff0, v0, j0);
+                    if (col1 && 16 * syi + 8 + y < a.H) put(rowp + voff1, v1, j1);
                 }
             }
         }

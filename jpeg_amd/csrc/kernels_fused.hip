@@ -30,6 +30,9 @@ namespace jpeg_amd {
 namespace {
 
 constexpr int kThreads = 256;
+// trunc(clamp(x, 0, 255)) == saturating round-to-nearest(x + kTruncBias) for the R and B
+// channel values x = y + m c (see k_luma_fused and tests/test_colour_rounding.py)
+constexpr float kTruncBias = -0.5f + 0.0009765625f;
 constexpr int TBX = 32;  // luma blocks per tile row   (tile = 256 x 64 px)
 constexpr int TBY = 8;   // luma blocks per tile column
 
@@ -295,25 +298,18 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             }
         }
 
-        // ---- luma: dequantise + IDCT; clamp + truncate == saturating convert of floor(v) ----
-        uint32_t ypk[16];  // ypk[2*y + h]: samples 4h..4h+3 of row y
-        {
-            float g[64];
-            idct_block(w, sq, 128.5f, g);
+        // ---- luma: dequantise + IDCT, clamp + truncate (decode.swift:4121-4122), kept as
+        //      integer-valued floats for the colour matrix ----
+        float yv[64];
+        idct_block(w, sq, 128.5f, yv);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                uint32_t p = 0;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) p = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[4 * i + x]), x, p);
-                ypk[i] = p;
-            }
-        }
+        for (int i = 0; i < 64; ++i) yv[i] = floorf(__builtin_amdgcn_fmed3f(yv[i], 0.0f, 255.0f));
 
         // Pin the IDCT HERE: LLVM otherwise sinks it below the waits / DMA (its results are first
         // used in the colour phase) and the wave would park on the chroma rows before doing any
         // arithmetic instead of letting them land during the IDCT.
 #pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(ypk[i]));
+        for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(yv[i]));
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- the chroma rows have landed (they are the only VM operations in flight) ----
@@ -405,17 +401,22 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             uint32_t d[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
-                const uint32_t yw = ypk[2 * y + (x >> 2)];
-                const float yy = (x & 3) == 0 ? ubyte<0>(yw) : (x & 3) == 1 ? ubyte<1>(yw)
-                                 : (x & 3) == 2 ? ubyte<2>(yw) : ubyte<3>(yw);
+                const float yy = yv[8 * y + x];
                 float c0, c1, c2;
                 if constexpr (MODE == 1) {
                     if constexpr (CHROMA) {
                         const float pb = cv[0][x], pr = cv[1][x];
-                        // jpeg.swift:441-453, op for op (the 0.0 * c terms are exact no-ops)
-                        c0 = floorf(yy + 1.40200f * pr);
+                        // jpeg.swift:441-453, op for op (the 0.0 * c terms are exact no-ops).
+                        // v_cvt_pk_u8_f32 rounds to nearest-even and saturates; the reference
+                        // clamps and TRUNCATES.  G is floored first.  For R and B the bias
+                        // kTruncBias = -0.5 + 2^-10 added to y turns round-to-nearest into
+                        // truncation for EVERY (y, c) in [0,255] x [-128,127]: the products
+                        // 1.402 c / 1.772 c never come closer than 0.004 to an integer
+                        // (verified exhaustively by tests/test_colour_rounding.py).
+                        const float yb = yy + kTruncBias;
+                        c0 = yb + 1.40200f * pr;
                         c1 = floorf((yy + -0.34414f * pb) + -0.71414f * pr);
-                        c2 = floorf(yy + 1.77200f * pb);
+                        c2 = yb + 1.77200f * pb;
                     } else {
                         c0 = c1 = c2 = yy;  // cb = cr = 128: every matrix term is +-0
                     }

@@ -1,0 +1,49 @@
+"""Exhaustive CPU proof of the rounding shortcut used by k_luma_fused (kernels_fused.hip).
+
+The reference clamps to [0, 255] and TRUNCATES the colour-matrix result (jpeg.swift:343-354,
+441-453).  gfx950's v_cvt_pk_u8_f32 rounds to nearest-even and saturates (tools/probe_isa.hip).
+For the R and B channels, x = y + m*c with y in [0, 255], c in [-128, 127] integers, the kernel
+evaluates sat_rne((y + kTruncBias) + m*c) with kTruncBias = -0.5 + 2^-10 instead of
+trunc(clamp(y + m*c)).  This test checks EVERY (y, c) pair for both channels in binary32, and
+documents that the same shortcut is NOT valid for G (two products), which the kernel floors.
+"""
+import numpy as np
+
+f32 = np.float32
+BIAS = f32(-0.5) + f32(2.0 ** -10)      # kTruncBias in kernels_fused.hip
+
+
+def _ref(x):   # clamp then truncate toward zero
+    return np.clip(x, f32(0), f32(255)).astype(np.int32)
+
+
+def _hw(z):    # v_cvt_pk_u8_f32: round to nearest even, saturate
+    return np.clip(np.rint(z), 0, 255).astype(np.int32)
+
+
+def test_bias_is_exactly_representable_and_exact_when_added():
+    y = np.arange(256, dtype=f32)
+    assert f32(BIAS) == BIAS
+    assert np.all((y + BIAS).astype(np.float64) == y.astype(np.float64) + np.float64(BIAS))
+
+
+def test_red_and_blue_every_input():
+    y = np.arange(256, dtype=f32)[:, None]
+    c = np.arange(-128, 128, dtype=f32)[None, :]
+    for m in (f32(1.40200), f32(1.77200)):
+        p = (m * c).astype(f32)                       # one rounding, as in the reference
+        want = _ref((y + p).astype(f32))
+        got = _hw(((y + BIAS).astype(f32) + p).astype(f32))
+        assert np.array_equal(want, got)
+
+
+def test_green_needs_the_floor():
+    y = np.arange(256, dtype=f32)[:, None, None]
+    pb = np.arange(-128, 128, dtype=f32)[None, :, None]
+    pr = np.arange(-128, 128, dtype=f32)[None, None, :]
+    q1 = (f32(-0.34414) * pb).astype(f32)
+    q2 = (f32(-0.71414) * pr).astype(f32)
+    x = ((y + q1).astype(f32) + q2).astype(f32)
+    z = (((y + BIAS).astype(f32) + q1).astype(f32) + q2).astype(f32)
+    assert (_ref(x) != _hw(z)).any()                  # the shortcut would be wrong here ...
+    assert np.array_equal(_ref(x), _hw(np.floor(x)))  # ... floor + saturating convert is exact

@@ -197,13 +197,10 @@ def main():
     ctx = J.Context(local)
 
     # quantisation tables: rank 0 owns them, RCCL broadcast over xGMI is the only collective
+    from jpeg_amd import dist as jd
     q_np = np.stack([J.compression_quanta("luminance", 1.0), J.compression_quanta("chrominance", 1.0)])
-    if rank == 0:
-        d_quanta = torch.from_numpy(q_np.view(np.int16)).to(dev)
-    else:
-        d_quanta = torch.zeros((2, 64), dtype=torch.int16, device=dev)
+    d_quanta = jd.broadcast_quanta(q_np if rank == 0 else 2, 0, dev, dist)
     if dist is not None:
-        dist.broadcast(d_quanta, src=0)
         assert (d_quanta.cpu().numpy().view(np.uint16) == q_np).all()
 
     if args.workload == "c3":
@@ -221,10 +218,7 @@ def main():
         wl.step()
     wall, gpu_ms = time_region(ctx, wl.step, args.steps, sync, barrier)
 
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    wall_max = jd.max_over_ranks(wall, dev, dist)
 
     result = None
     if rank == 0:

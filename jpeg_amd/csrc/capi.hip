@@ -485,6 +485,13 @@ int jpeg_amd_encode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_ima
         offset[p] = total;
         total += align256(plane_samples(L, p) * (size_t)n_images * sizeof(uint16_t));
     }
+    if (fused_encode_supported(*L)) {
+        PlaneSetMut cs{};
+        for (int p = 0; p < L->nplanes; ++p) { cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p]; }
+        JA_HIP(ctx, launch_fused_encode(ctx->stream, n_images, *L, d_pixels, pixel_stride,
+                                        color == JPEG_AMD_COLOR_RGB8, QuantaRef{d_quanta, quanta_stride}, cs));
+        return JPEG_AMD_OK;
+    }
     JA_TRY(ensure_scratch(ctx, total));
     PlaneSetMut ps{};
     for (int p = 0; p < L->nplanes; ++p) {

@@ -66,6 +66,13 @@ hipError_t launch_decompose(hipStream_t stream, int n_images, const jpeg_amd_lay
                             const void *d_in, size_t in_stride_bytes, PixelKind in_kind,
                             const PlaneSetMut &planes);
 
+// Fused pixels -> Spectral (kernels_encode.hip): 8-bit y8 images, and ycc8 images with
+// full-factor luma and 1x / 2x subsampled chroma.
+bool       fused_encode_supported(const jpeg_amd_layout &layout);
+hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_layout &layout,
+                               const uint8_t *d_pixels, size_t pixel_stride, bool rgb, QuantaRef q,
+                               const PlaneSetMut &coef);
+
 // a15..a17: FDCT + quantise of one plane.
 hipError_t launch_fdct_plane(hipStream_t stream, int n_images, const uint16_t *d_plane,
                              size_t plane_stride, QuantaRef q, int qi, int ux, int uy,

@@ -1,0 +1,311 @@
+// kernels_encode.hip -- fused pixels -> Spectral fast path for the built-in 8-bit formats.
+//
+// Replaces Rectangular.pack(...) -> decomposed() -> Planar.fdct(quanta:) (encode.swift:453,
+// 389, 353) for ycc8 images whose luma has the full sampling factor and whose chroma planes
+// are subsampled 1x or 2x per axis, and for y8 images, without materialising Rectangular /
+// Planar in HBM: one kernel, RGB8 (or YCbCr8) bytes in, quantised zigzag coefficients out.
+//
+// One workgroup = one tile of 32 x 16 luma blocks (256 x 128 px); a work-item converts and
+// transforms two luma blocks (rows t/32 and t/32 + 8 of the tile), pools their chroma into an
+// LDS tile (box filter of encode.swift:402-423: the window of a 2x subsampled sample lies
+// inside one 8x8 luma block, so no halo is needed), and after one barrier transforms its
+// share of the tile's chroma blocks (one per work-item for 4:2:0).
+//
+// Arithmetic is the reference's, op for op (-ffp-contract=off): colour matrix
+// jpeg.swift:463-478, FDCT encode.swift:123-196, true IEEE division by the modulated table and
+// round-half-away (encode.swift:225-240).  Exact simplifications:
+//   - `pointwiseMin(limit, v)` is the identity for 8-bit samples (v <= 255 = limit);
+//   - the colour results need no clamp before truncation: Y in [0, 255.0001], Cb/Cr in
+//     [0.5, 255.5], so floor() alone is clamp + truncate;
+//   - Float(sum) / Float(n) truncated, n in {1, 2, 4}, is floor(sum * (1/n)) exactly.
+#pragma clang fp contract(off)
+
+#include "dct.hpp"
+#include "kernels.hpp"
+
+namespace jpeg_amd {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int ETX = 32;  // luma blocks per tile row
+constexpr int ETY = 16;  // luma blocks per tile column
+
+struct EncArgs {
+    const uint8_t *px;
+    size_t px_stride;
+    int W, H;
+    int16_t *coef[3];
+    size_t coef_stride[3];
+    int ux[3], uy[3];
+    const uint16_t *quanta;
+    size_t quanta_stride;
+    int qi[3];
+    int tiles_x;
+};
+
+// natural index (8h + k) of zigzag slot z (inverse of zigzag_of), usable at compile time
+__host__ __device__ constexpr int natural_of(int z)
+{
+    for (int h = 0; h < 8; ++h)
+        for (int k = 0; k < 8; ++k)
+            if (zigzag_of(k, h) == z) return 8 * h + k;
+    return 0;
+}
+
+template <int N>
+__device__ __forceinline__ float ubyte(uint32_t v)
+{
+    return (float)((v >> (8 * N)) & 0xffu);  // v_cvt_f32_ubyteN
+}
+
+// RGB.ycc -- jpeg.swift:463-478: x = ((m0 + m_r r) + m_g g) + m_b b, then clamp + truncate.
+__device__ __forceinline__ void rgb_to_ycc(float r, float g, float b, float &y, float &cb, float &cr)
+{
+    y  = floorf((0.2990f * r + 0.5870f * g) + 0.1140f * b);          // `0 + x` is exact
+    cb = floorf(((128.0f + -0.1687f * r) + -0.3313f * g) + 0.5000f * b);
+    cr = floorf(((128.0f + 0.5000f * r) + -0.4187f * g) + -0.0813f * b);
+}
+
+// FDCT + quantise + zigzag scatter of one block held as 64 floats g[8y + x]; q = modulated
+// table (scale 8) in LDS, natural order.  encode.swift:199-248.
+__device__ __forceinline__ void fdct_quantise_store(const float (&g)[64], const float *q, int16_t *dst)
+{
+    float H[64];
+    fdct_block(g, 1024.0f, H);  // level = 2^(P-1) * 8, P = 8 (encode.swift:215-216)
+    uint32_t w[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        // zigzag slots 2m, 2m+1 <- natural positions (compile-time after unrolling)
+        const int n0 = natural_of(2 * m), n1 = natural_of(2 * m + 1);
+        const int c0 = (int)round_half_away(H[n0] / q[n0]);
+        const int c1 = (int)round_half_away(H[n1] / q[n1]);
+        w[m] = ((uint32_t)c0 & 0xffffu) | ((uint32_t)c1 << 16);
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// SX, SY: chroma subsampling (1 or 2) per axis; RGB: input is RGB8 (else YCbCr8);
+// CHROMA = false: single-plane image (only Y is produced);
+// FASTIN: W % 8 == 0 and 8-byte aligned rows (vector loads for blocks inside the image).
+template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN>
+__global__ __launch_bounds__(kThreads) void k_encode_fused(EncArgs a)
+{
+    constexpr int CW = ETX * 8 / SX, CH = ETY * 8 / SY;  // chroma samples per tile
+    constexpr int CPITCH = CW / 4;                       // dwords per LDS row
+    constexpr bool INTHREAD = SX == 1 && SY == 1;        // 4:4:4: chroma block == the luma block's pixels
+    __shared__ uint32_t sc[(CHROMA && !INTHREAD) ? 2 * CH * CPITCH : 1];
+    __shared__ float sq[3][64];
+
+    const int img = blockIdx.y;
+    const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
+    const int lbx = threadIdx.x & (ETX - 1), lby0 = threadIdx.x / ETX;
+
+    if (threadIdx.x < 192 && (CHROMA || threadIdx.x < 64)) {
+        const int t = threadIdx.x >> 6, k = threadIdx.x & 7, h = (threadIdx.x >> 3) & 7;
+        sq[t][threadIdx.x & 63] = modulate_entry(k, h, 8.0f,
+                                                 a.quanta[img * a.quanta_stride + 64 * a.qi[t] + zigzag_of(k, h)]);
+    }
+    __syncthreads();
+
+    const uint8_t *base = a.px + img * a.px_stride;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int lby = lby0 + 8 * half;
+        const int bx = txi * ETX + lbx, by = tyi * ETY + lby;
+        float yv[64];
+        uint32_t cpk[2][16];  // 4:4:4 only: the block's Cb / Cr samples packed 4 per dword
+
+        // one pixel row of the block: Y stays in registers for the FDCT; Cb / Cr are pooled by
+        // the box filter (every SY rows) into the LDS tile, or packed for the in-thread path
+        float crow[2][2][8];  // [plane][row parity][x]
+        auto emit_row = [&](int y, const float (&c0)[8], const float (&c1)[8], const float (&c2)[8]) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                float yy, cb, cr;
+                if constexpr (RGB) rgb_to_ycc(c0[x], c1[x], c2[x], yy, cb, cr);
+                else { yy = c0[x]; cb = c1[x]; cr = c2[x]; }
+                yv[8 * y + x] = yy;
+                crow[0][y & 1][x] = cb;
+                crow[1][y & 1][x] = cr;
+            }
+            if constexpr (CHROMA && INTHREAD) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v = __builtin_amdgcn_cvt_pk_u8_f32(crow[pl][y & 1][4 * d + i], i, v);
+                        cpk[pl][2 * y + d] = v;
+                    }
+            } else if constexpr (CHROMA) {
+                if (SY == 1 || (y & 1)) {
+                    constexpr float inv = 1.0f / (float)(SX * SY);
+                    const int j = y / SY;
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        uint32_t packed[(8 / SX + 3) / 4] = {};
+#pragma unroll
+                        for (int i = 0; i < 8 / SX; ++i) {
+                            float sum;
+                            if constexpr (SX == 2 && SY == 2)
+                                sum = (crow[pl][0][2 * i] + crow[pl][0][2 * i + 1]) + (crow[pl][1][2 * i] + crow[pl][1][2 * i + 1]);
+                            else if constexpr (SX == 2)
+                                sum = crow[pl][y & 1][2 * i] + crow[pl][y & 1][2 * i + 1];
+                            else
+                                sum = crow[pl][0][i] + crow[pl][1][i];
+                            // integer sum of <= 4 bytes, exact; Float(sum) / n truncated
+                            packed[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(sum * inv), i & 3, packed[i >> 2]);
+                        }
+                        uint32_t *row = sc + (pl * CH + lby * (8 / SY) + j) * CPITCH + lbx * (8 / SX) / 4;
+#pragma unroll
+                        for (int d = 0; d < (8 / SX + 3) / 4; ++d) row[d] = packed[d];
+                    }
+                }
+            }
+        };
+
+        // ---- load 8x8 pixels (edge replicate: encode.swift:415-417) and convert ----
+        const bool inside = 8 * bx + 8 <= a.W && 8 * by + 8 <= a.H;
+        if (FASTIN && inside) {
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                const uint2 *row = reinterpret_cast<const uint2 *>(base + ((size_t)(8 * by + y) * a.W + 8 * bx) * 3);
+                const uint2 p0 = row[0], p1 = row[1], p2 = row[2];
+                const uint32_t d[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+                float c[3][8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const int byte = 3 * x + ch;
+                        const uint32_t dw = d[byte >> 2];
+                        c[ch][x] = (byte & 3) == 0 ? ubyte<0>(dw) : (byte & 3) == 1 ? ubyte<1>(dw)
+                                   : (byte & 3) == 2 ? ubyte<2>(dw) : ubyte<3>(dw);
+                    }
+                emit_row(y, c[0], c[1], c[2]);
+            }
+        } else {
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                const int gy = min(8 * by + y, a.H - 1);
+                float c[3][8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const int gx = min(8 * bx + x, a.W - 1);
+                    const uint8_t *p = base + ((size_t)gy * a.W + gx) * 3;
+                    c[0][x] = (float)p[0]; c[1][x] = (float)p[1]; c[2][x] = (float)p[2];
+                }
+                emit_row(y, c[0], c[1], c[2]);
+            }
+        }
+
+        // ---- luma (and 4:4:4 chroma) blocks of this position ----
+        if (bx < a.ux[0] && by < a.uy[0])
+            fdct_quantise_store(yv, sq[0], a.coef[0] + img * a.coef_stride[0] + (size_t)64 * (by * a.ux[0] + bx));
+        if constexpr (CHROMA && INTHREAD) {
+#pragma unroll 1
+            for (int pl = 0; pl < 2; ++pl) {
+                if (bx >= a.ux[1 + pl] || by >= a.uy[1 + pl]) continue;
+                float g[64];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t v = pl ? cpk[1][i] : cpk[0][i];
+                    g[4 * i + 0] = ubyte<0>(v); g[4 * i + 1] = ubyte<1>(v);
+                    g[4 * i + 2] = ubyte<2>(v); g[4 * i + 3] = ubyte<3>(v);
+                }
+                fdct_quantise_store(g, sq[1 + pl],
+                                    a.coef[1 + pl] + img * a.coef_stride[1 + pl] + (size_t)64 * (by * a.ux[1 + pl] + bx));
+            }
+        }
+    }
+
+    if constexpr (CHROMA && !INTHREAD) {
+        __syncthreads();
+        constexpr int CBX = ETX / SX, CBY = ETY / SY;  // chroma blocks per tile and plane
+#pragma unroll 1
+        for (int c = threadIdx.x; c < 2 * CBX * CBY; c += kThreads) {
+            const int pl = c / (CBX * CBY), r = c - pl * (CBX * CBY);
+            const int cby = r / CBX, cbx = r - cby * CBX;
+            const int bx = txi * CBX + cbx, by = tyi * CBY + cby;
+            if (bx >= a.ux[1 + pl] || by >= a.uy[1 + pl]) continue;
+            float g[64];
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                const uint32_t *row = sc + (pl * CH + 8 * cby + y) * CPITCH + 2 * cbx;
+                const uint32_t d0 = row[0], d1 = row[1];
+                g[8 * y + 0] = ubyte<0>(d0); g[8 * y + 1] = ubyte<1>(d0);
+                g[8 * y + 2] = ubyte<2>(d0); g[8 * y + 3] = ubyte<3>(d0);
+                g[8 * y + 4] = ubyte<0>(d1); g[8 * y + 5] = ubyte<1>(d1);
+                g[8 * y + 6] = ubyte<2>(d1); g[8 * y + 7] = ubyte<3>(d1);
+            }
+            fdct_quantise_store(g, sq[1 + pl],
+                                a.coef[1 + pl] + img * a.coef_stride[1 + pl] + (size_t)64 * (by * a.ux[1 + pl] + bx));
+        }
+    }
+}
+
+}  // namespace
+
+bool fused_encode_supported(const jpeg_amd_layout &L)
+{
+    if (L.precision != 8) return false;
+    auto units = [](int size, int stride) { return size / stride + (size % stride != 0 ? 1 : 0); };
+    for (int p = 0; p < L.nplanes; ++p) {
+        if (L.units_x[p] != units(L.width * L.factor_x[p], 8 * L.scale_x)) return false;
+        if (L.units_y[p] != units(L.height * L.factor_y[p], 8 * L.scale_y)) return false;
+    }
+    if (L.factor_x[0] != L.scale_x || L.factor_y[0] != L.scale_y) return false;  // luma at full resolution
+    if (L.nplanes == 1) return true;
+    if (L.nplanes != 3) return false;
+    if (L.scale_x > 2 || L.scale_y > 2) return false;
+    for (int p = 1; p < 3; ++p)
+        if (L.factor_x[p] != 1 || L.factor_y[p] != 1) return false;
+    return true;
+}
+
+hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_layout &L,
+                               const uint8_t *d_pixels, size_t pixel_stride, bool rgb, QuantaRef q,
+                               const PlaneSetMut &coef)
+{
+    EncArgs a{};
+    a.px = d_pixels; a.px_stride = pixel_stride; a.W = L.width; a.H = L.height;
+    a.quanta = q.d_quanta; a.quanta_stride = q.image_stride;
+    for (int p = 0; p < 3; ++p) {
+        const int s = p < L.nplanes ? p : 0;
+        a.coef[p] = static_cast<int16_t *>(coef.ptr[s]);
+        a.coef_stride[p] = coef.stride[s];
+        a.ux[p] = p < L.nplanes ? L.units_x[p] : 0;
+        a.uy[p] = p < L.nplanes ? L.units_y[p] : 0;
+        a.qi[p] = L.qi[s];
+    }
+    const bool chroma = L.nplanes == 3;
+    const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;
+    // tiles must cover the luma blocks AND the pixels under every chroma block
+    const int need_x = chroma ? max(a.ux[0], sx * a.ux[1]) : a.ux[0];
+    const int need_y = chroma ? max(a.uy[0], sy * a.uy[1]) : a.uy[0];
+    a.tiles_x = (need_x + ETX - 1) / ETX;
+    const int tiles_y = (need_y + ETY - 1) / ETY;
+    if (a.tiles_x * tiles_y == 0 || n_images == 0) return hipSuccess;
+    const dim3 grid(a.tiles_x * tiles_y, n_images);
+    const bool fast = (L.width & 7) == 0 && (pixel_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 7) == 0;
+#define JA_E(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_>), grid, dim3(kThreads), 0, stream, a)
+#define JA_E2(RGB_, F_)                                         \
+    do {                                                        \
+        if (!chroma) JA_E(1, 1, RGB_, false, F_);               \
+        else if (sx == 2 && sy == 2) JA_E(2, 2, RGB_, true, F_); \
+        else if (sx == 2 && sy == 1) JA_E(2, 1, RGB_, true, F_); \
+        else if (sx == 1 && sy == 2) JA_E(1, 2, RGB_, true, F_); \
+        else JA_E(1, 1, RGB_, true, F_);                        \
+    } while (0)
+    if (rgb) { if (fast) JA_E2(true, true); else JA_E2(true, false); }
+    else     { if (fast) JA_E2(false, true); else JA_E2(false, false); }
+#undef JA_E2
+#undef JA_E
+    return hipGetLastError();
+}
+
+}  // namespace jpeg_amd

@@ -67,20 +67,55 @@ __device__ __forceinline__ void rgb_to_ycc(float r, float g, float b, float &y, 
     cr = floorf(((128.0f + 0.5000f * r) + -0.4187f * g) + -0.0813f * b);
 }
 
-// FDCT + quantise + zigzag scatter of one block held as 64 floats g[8y + x]; q = modulated
-// table (scale 8) in LDS, natural order.  encode.swift:199-248.
-__device__ __forceinline__ void fdct_quantise_store(const float (&g)[64], const float *q, int16_t *dst)
+// FDCT + quantise + zigzag scatter of one block held as 64 floats g[8y + x]; q / rq = modulated
+// table (scale 8) and its correctly rounded reciprocal, in LDS, TRANSPOSED (q[8k + h]) so that the
+// 8 entries one vertical pass needs are two 16-byte reads.  encode.swift:199-248.
+//
+// Quantiser: the reference computes RN(H / q) with a true division and rounds half away from
+// zero.  Here  y0 = H * rq;  e = fma(-y0, q, H);  y1 = fma(e, rq, y0)  (Markstein's correction
+// step) and  n = trunc(y1 + copysign(pred(0.5), y1)).  tools/verify_div.hip proves by exhaustion
+// on the GPU that n equals the reference's integer for EVERY float numerator below 2^17 and
+// EVERY divisor an 8-bit quantisation table can produce (7140 divisors x 1.2e9 numerators,
+// profiles/r01_verify_div.txt); the fused kernel only runs for 8-bit formats.
+__device__ __forceinline__ void fdct_quantise_store(const float (&g)[64], const float *q, const float *rq,
+                                                    int16_t *dst)
 {
-    float H[64];
-    fdct_block(g, 1024.0f, H);  // level = 2^(P-1) * 8, P = 8 (encode.swift:215-216)
-    uint32_t w[32];
+    float f[64];  // f[8k + y]: horizontal pass (encode.swift:193), level shift 2^(P-1) * 8
 #pragma unroll
-    for (int m = 0; m < 32; ++m) {
-        // zigzag slots 2m, 2m+1 <- natural positions (compile-time after unrolling)
-        const int n0 = natural_of(2 * m), n1 = natural_of(2 * m + 1);
-        const int c0 = (int)round_half_away(H[n0] / q[n0]);
-        const int c1 = (int)round_half_away(H[n1] / q[n1]);
-        w[m] = ((uint32_t)c0 & 0xffffu) | ((uint32_t)c1 << 16);
+    for (int y = 0; y < 8; ++y) {
+        float r[8], res[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) r[x] = g[8 * y + x];
+        fdct8<true>(r, 1024.0f, res);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[8 * k + y] = res[k];
+    }
+    // Opaque empty asm statements pin the program order: without them LLVM re-orders the pure
+    // arithmetic of all eight columns around the table reads and needs > 200 VGPRs (spills).
+#pragma unroll
+    for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(f[i]));
+    uint32_t w[32];   // 64 quantised coefficients, zigzag order, packed in pairs
+#pragma unroll
+    for (int m = 0; m < 32; ++m) w[m] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        __builtin_amdgcn_sched_barrier(0);
+        float r[8], res[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) r[y] = f[8 * k + y];
+        fdct8<false>(r, 0.0f, res);  // vertical pass (encode.swift:194)
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const float qq = q[8 * k + h], rr = rq[8 * k + h];
+            const float y0 = res[h] * rr;
+            const float e  = __builtin_fmaf(-y0, qq, res[h]);
+            const float y1 = __builtin_fmaf(e, rr, y0);
+            const int ci = (int)(y1 + __builtin_copysignf(0.49999997f, y1));  // the cast truncates
+            const int z = zigzag_of(k, h);                                     // scatter (encode.swift:236-239)
+            if (z & 1) w[z >> 1] |= (uint32_t)ci << 16;
+            else w[z >> 1] |= (uint32_t)ci & 0xffffu;
+            asm volatile("" : "+v"(w[z >> 1]));
+        }
     }
     uint4 *o = reinterpret_cast<uint4 *>(dst);
 #pragma unroll
@@ -91,13 +126,14 @@ __device__ __forceinline__ void fdct_quantise_store(const float (&g)[64], const 
 // CHROMA = false: single-plane image (only Y is produced);
 // FASTIN: W % 8 == 0 and 8-byte aligned rows (vector loads for blocks inside the image).
 template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN>
-__global__ __launch_bounds__(kThreads) void k_encode_fused(EncArgs a)
+__global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
 {
     constexpr int CW = ETX * 8 / SX, CH = ETY * 8 / SY;  // chroma samples per tile
     constexpr int CPITCH = CW / 4;                       // dwords per LDS row
     constexpr bool INTHREAD = SX == 1 && SY == 1;        // 4:4:4: chroma block == the luma block's pixels
     __shared__ uint32_t sc[(CHROMA && !INTHREAD) ? 2 * CH * CPITCH : 1];
-    __shared__ float sq[3][64];
+    __shared__ float sq[3][64];   // modulated tables (scale 8) ...
+    __shared__ float sr[3][64];   // ... and their correctly rounded reciprocals
 
     const int img = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
@@ -105,8 +141,9 @@ __global__ __launch_bounds__(kThreads) void k_encode_fused(EncArgs a)
 
     if (threadIdx.x < 192 && (CHROMA || threadIdx.x < 64)) {
         const int t = threadIdx.x >> 6, k = threadIdx.x & 7, h = (threadIdx.x >> 3) & 7;
-        sq[t][threadIdx.x & 63] = modulate_entry(k, h, 8.0f,
-                                                 a.quanta[img * a.quanta_stride + 64 * a.qi[t] + zigzag_of(k, h)]);
+        const float qv = modulate_entry(k, h, 8.0f, a.quanta[img * a.quanta_stride + 64 * a.qi[t] + zigzag_of(k, h)]);
+        sq[t][8 * k + h] = qv;                 // transposed: [k][h]
+        sr[t][8 * k + h] = 1.0f / qv;          // IEEE division: RN(1 / q)
     }
     __syncthreads();
 
@@ -168,44 +205,58 @@ __global__ __launch_bounds__(kThreads) void k_encode_fused(EncArgs a)
             }
         };
 
-        // ---- load 8x8 pixels (edge replicate: encode.swift:415-417) and convert ----
+        // ---- load 8x8 pixels as 8 rows of 24 bytes (edge replicate: encode.swift:415-417).
+        //      All loads first (one latency), then one row at a time: left alone, the scheduler
+        //      converts all 192 bytes to floats up front. ----
+        uint32_t pix[8][6];
         const bool inside = 8 * bx + 8 <= a.W && 8 * by + 8 <= a.H;
         if (FASTIN && inside) {
 #pragma unroll
             for (int y = 0; y < 8; ++y) {
                 const uint2 *row = reinterpret_cast<const uint2 *>(base + ((size_t)(8 * by + y) * a.W + 8 * bx) * 3);
                 const uint2 p0 = row[0], p1 = row[1], p2 = row[2];
-                const uint32_t d[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
-                float c[3][8];
-#pragma unroll
-                for (int x = 0; x < 8; ++x)
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        const int byte = 3 * x + ch;
-                        const uint32_t dw = d[byte >> 2];
-                        c[ch][x] = (byte & 3) == 0 ? ubyte<0>(dw) : (byte & 3) == 1 ? ubyte<1>(dw)
-                                   : (byte & 3) == 2 ? ubyte<2>(dw) : ubyte<3>(dw);
-                    }
-                emit_row(y, c[0], c[1], c[2]);
+                pix[y][0] = p0.x; pix[y][1] = p0.y; pix[y][2] = p1.x; pix[y][3] = p1.y; pix[y][4] = p2.x; pix[y][5] = p2.y;
             }
         } else {
+            // edge blocks / unaligned images: clamped byte loads, packed into the same layout
 #pragma unroll
             for (int y = 0; y < 8; ++y) {
-                const int gy = min(8 * by + y, a.H - 1);
-                float c[3][8];
+                __builtin_amdgcn_sched_barrier(0);
+                const uint8_t *row = base + (size_t)min(8 * by + y, a.H - 1) * a.W * 3;
 #pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    const int gx = min(8 * bx + x, a.W - 1);
-                    const uint8_t *p = base + ((size_t)gy * a.W + gx) * 3;
-                    c[0][x] = (float)p[0]; c[1][x] = (float)p[1]; c[2][x] = (float)p[2];
+                for (int d = 0; d < 6; ++d) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int byte = 4 * d + i, x = byte / 3, ch = byte - 3 * x;
+                        v |= (uint32_t)row[3 * min(8 * bx + x, a.W - 1) + ch] << (8 * i);
+                    }
+                    pix[y][d] = v;
                 }
-                emit_row(y, c[0], c[1], c[2]);
             }
+        }
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            __builtin_amdgcn_sched_barrier(0);
+            float c[3][8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const int byte = 3 * x + ch;
+                    const uint32_t dw = pix[y][byte >> 2];
+                    c[ch][x] = (byte & 3) == 0 ? ubyte<0>(dw) : (byte & 3) == 1 ? ubyte<1>(dw)
+                               : (byte & 3) == 2 ? ubyte<2>(dw) : ubyte<3>(dw);
+                }
+            emit_row(y, c[0], c[1], c[2]);
+#pragma unroll
+            for (int x = 0; x < 8; ++x) asm volatile("" : "+v"(yv[8 * y + x]));
         }
 
         // ---- luma (and 4:4:4 chroma) blocks of this position ----
+        __builtin_amdgcn_sched_barrier(0);
         if (bx < a.ux[0] && by < a.uy[0])
-            fdct_quantise_store(yv, sq[0], a.coef[0] + img * a.coef_stride[0] + (size_t)64 * (by * a.ux[0] + bx));
+            fdct_quantise_store(yv, sq[0], sr[0], a.coef[0] + img * a.coef_stride[0] + (size_t)64 * (by * a.ux[0] + bx));
         if constexpr (CHROMA && INTHREAD) {
 #pragma unroll 1
             for (int pl = 0; pl < 2; ++pl) {
@@ -217,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void k_encode_fused(EncArgs a)
                     g[4 * i + 0] = ubyte<0>(v); g[4 * i + 1] = ubyte<1>(v);
                     g[4 * i + 2] = ubyte<2>(v); g[4 * i + 3] = ubyte<3>(v);
                 }
-                fdct_quantise_store(g, sq[1 + pl],
+                fdct_quantise_store(g, sq[1 + pl], sr[1 + pl],
                                     a.coef[1 + pl] + img * a.coef_stride[1 + pl] + (size_t)64 * (by * a.ux[1 + pl] + bx));
             }
         }
@@ -242,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void k_encode_fused(EncArgs a)
                 g[8 * y + 4] = ubyte<0>(d1); g[8 * y + 5] = ubyte<1>(d1);
                 g[8 * y + 6] = ubyte<2>(d1); g[8 * y + 7] = ubyte<3>(d1);
             }
-            fdct_quantise_store(g, sq[1 + pl],
+            fdct_quantise_store(g, sq[1 + pl], sr[1 + pl],
                                 a.coef[1 + pl] + img * a.coef_stride[1 + pl] + (size_t)64 * (by * a.ux[1 + pl] + bx));
         }
     }

@@ -339,6 +339,27 @@ def extras(J, ctx, d_quanta, q_np, sync, args):
     out["c4_encode_4096"] = {"ms": round(ms, 4), "Mpixels_per_s": round(w * h / ms / 1e3, 1),
                              "GB_per_s": round(nbytes / ms / 1e6, 1),
                              "frac_hbm": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    # parity of the frame just encoded: coefficient equality with the oracle (PSNR vs the
+    # reference is then infinite), plus the PSNR of decode(encode(x)) against x for the record
+    try:
+        from oracle import oracle as O
+        rgb0 = px[0].cpu().numpy()
+        want = O.encode(rgb0, (w, h), [(2, 2), (1, 1), (1, 1)], [q_np[0], q_np[1], q_np[1]],
+                        threads=min(64, os.cpu_count() or 1))
+        st = lib.jpeg_amd_encode_batch(ctx.handle, C.byref(L), 1, px[0].data_ptr(), 0, _lib.COLOR_RGB8,
+                                       d_quanta.data_ptr(), 0, 2, _lib.ptr_array([c[0].data_ptr() for c in coefs]), zero)
+        assert st == 0
+        sync()
+        same = all((c[0].cpu().numpy().reshape(wp.shape) == wp).all() for c, wp in zip(coefs, want))
+        out["c4_encode_4096"]["coefficients_equal_oracle"] = bool(same)
+        back = torch.empty(w * h * 3, dtype=torch.uint8, device=dev)
+        st = lib.jpeg_amd_decode_batch(ctx.handle, C.byref(L), 1, _lib.ptr_array([c[0].data_ptr() for c in coefs]), zero,
+                                       d_quanta.data_ptr(), 0, 2, 0, _lib.COLOR_RGB8, back.data_ptr(), 0)
+        assert st == 0
+        err = (back.view(-1, 3).float() - px[0].float()).pow(2).mean().item()
+        out["c4_encode_4096"]["roundtrip_psnr_db"] = round(10 * np.log10(255.0 ** 2 / max(err, 1e-12)), 2)
+    except Exception as e:  # never let the side measurement break the headline line
+        out["c4_encode_4096"]["parity_error"] = repr(e)
     del px, coefs
 
     # C5-shaped batch on one GPU: 128 images of 1920x1080 (a quarter of the per-GPU share)

@@ -1,0 +1,90 @@
+"""GPU parity at BASELINE.json's full sizes (configs 3, 4 and a slice of config 5).
+
+The threaded oracle makes a direct comparison affordable on the GPU box's host (256 threads);
+size-independent properties are checked as well: a batch decodes to exactly what its images
+decode to one by one (independent images), and an image decodes to the same
+pixels wherever it sits in a batch (stride handling)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+THREADS = min(64, os.cpu_count() or 1)
+FACTORS = [(2, 2), (1, 1), (1, 1)]
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import jpeg_amd as J
+    from jpeg_amd import _lib, synth
+    ctx = J.Context(0)
+    q = np.stack([J.compression_quanta("luminance", 1.0), J.compression_quanta("chrominance", 1.0)])
+    d_q = torch.from_numpy(q.view(np.int16).copy()).to(ctx.torch_device)
+    layout = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    return dict(torch=torch, J=J, lib=_lib.lib(), _lib=_lib, synth=synth, ctx=ctx, q=q, d_q=d_q, layout=layout)
+
+
+def _decode_batch(e, size, planes, n):
+    torch, _lib = e["torch"], e["_lib"]
+    units = e["layout"].units(size)
+    L = e["layout"].c_layout(size, units, [0, 1, 1])
+    out = torch.empty((n, size[0] * size[1] * 3), dtype=torch.uint8, device=e["ctx"].torch_device)
+    st = e["lib"].jpeg_amd_decode_batch(e["ctx"].handle, C.byref(L), n, _lib.ptr_array([p.data_ptr() for p in planes]),
+                                       _lib.size_array([64 * a * b for a, b in units]), e["d_q"].data_ptr(), 0, 2, 0,
+                                       _lib.COLOR_RGB8, out.data_ptr(), size[0] * size[1] * 3)
+    assert st == 0
+    return out
+
+
+def _oracle_rgb(e, planes_np, size):
+    _, rect = O.decode(planes_np, [e["q"][0], e["q"][1], e["q"][1]], FACTORS, size, threads=THREADS)
+    return O.unpack_rgb8(rect, 3, threads=THREADS)
+
+
+def test_config3_one_8192x8192_image(env):
+    e = env
+    size = (8192, 8192)
+    planes = e["synth"].natural_planes_torch(e["layout"].units(size), 1, e["ctx"].torch_device, 31)
+    got = _decode_batch(e, size, planes, 1)[0].cpu().numpy().reshape(-1, 3)
+    want = _oracle_rgb(e, [p[0].cpu().numpy() for p in planes], size)
+    assert (got == want).all(), f"{(got != want).sum()} of {got.size} bytes differ"
+
+
+def test_config4_4096x4096_encode(env):
+    e = env
+    torch, _lib = e["torch"], e["_lib"]
+    size = (4096, 4096)
+    px = e["synth"].smooth_rgb_torch(size[0], size[1], 1, e["ctx"].torch_device)
+    units = e["layout"].units(size)
+    L = e["layout"].c_layout(size, units, [0, 1, 1])
+    coefs = [torch.empty(64 * a * b, dtype=torch.int16, device=e["ctx"].torch_device) for a, b in units]
+    st = e["lib"].jpeg_amd_encode_batch(e["ctx"].handle, C.byref(L), 1, px.data_ptr(), 0, _lib.COLOR_RGB8, e["d_q"].data_ptr(),
+                                       0, 2, _lib.ptr_array([c.data_ptr() for c in coefs]), _lib.size_array([0, 0, 0]))
+    assert st == 0
+    want = O.encode(px[0].cpu().numpy(), size, FACTORS, [e["q"][0], e["q"][1], e["q"][1]], threads=THREADS)
+    for c, w in zip(coefs, want):
+        assert (c.cpu().numpy().reshape(w.shape) == w).all()
+
+
+def test_config5_slice_batch_of_1080p(env):
+    """64 of config 5's 1920x1080 images (MCU grid 120 x 68, last MCU row half padded)."""
+    e = env
+    size, n = (1920, 1080), 64
+    planes = e["synth"].natural_planes_torch(e["layout"].units(size), n, e["ctx"].torch_device, 77)
+    batch = _decode_batch(e, size, planes, n)
+    # a few images against the oracle
+    for i in (0, 17, n - 1):
+        want = _oracle_rgb(e, [p[i].cpu().numpy() for p in planes], size)
+        assert (batch[i].cpu().numpy().reshape(-1, 3) == want).all(), f"image {i}"
+    # batch == images one by one (independent images; strides)
+    for i in (1, 40):
+        single = _decode_batch(e, size, [p[i:i + 1] for p in planes], 1)[0]
+        assert e["torch"].equal(single, batch[i])
+    # cheap whole-batch witness: every image differs from its neighbour (no aliasing of strides)
+    sums = batch.to(e["torch"].int64).sum(dim=1).cpu().numpy()
+    assert len(set(sums.tolist())) == n

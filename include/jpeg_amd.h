@@ -193,6 +193,34 @@ int jpeg_amd_host_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
                          const uint8_t *h_pixels, jpeg_amd_color color,
                          const uint16_t *h_quanta, int ntables, int16_t *const h_coef[]);
 
+/* ---- host side of the path's INPUT ("next" rows) -------------------------
+ * Huffman entropy decoding stays on the host CPU (north_star); these entry points turn a JPEG
+ * byte stream into the Spectral containers the kernels consume, like
+ * JPEG.Data.Spectral.decompress(stream:) does through JPEG.Context (decode.swift:3554-3961,
+ * 4315).  Baseline / extended sequential and progressive Huffman, restart intervals, 1..4
+ * components, 8-bit or 12-bit.  No GPU is needed for the first two. */
+typedef struct jpeg_amd_frame_info {
+    int32_t width, height, precision, ncomponents;
+    int32_t process;                          /* 0 baseline, 1 extended sequential, 2 progressive */
+    int32_t scale_x, scale_y;                 /* Layout.scale */
+    int32_t id[JPEG_AMD_MAX_PLANES];          /* component identifiers, frame order */
+    int32_t factor_x[JPEG_AMD_MAX_PLANES], factor_y[JPEG_AMD_MAX_PLANES];
+    int32_t units_x[JPEG_AMD_MAX_PLANES], units_y[JPEG_AMD_MAX_PLANES];
+    int32_t nscans, restart_interval;
+} jpeg_amd_frame_info;
+
+/* parse the headers (and walk the scans) without decoding: geometry for buffer allocation */
+int jpeg_amd_jpeg_inspect(const uint8_t *h_jpeg, size_t nbytes, jpeg_amd_frame_info *info);
+/* entropy-decode every scan into caller-allocated planes h_coef[c]: int16 [units_y][units_x][64]
+ * zigzag (zeroed here first); h_quanta[c] receives the table bound to component c (zigzag). */
+int jpeg_amd_jpeg_decode_spectral(const uint8_t *h_jpeg, size_t nbytes, int16_t *const h_coef[],
+                                  uint16_t h_quanta[][64], jpeg_amd_frame_info *info);
+/* Rectangular.decompress(stream:cosite:) + unpack(as:)  (decode.swift:4367, os.swift:375):
+ * JPEG bytes in, H*W colours of 3 bytes out (host memory); 8-bit images of 1 or 3 components. */
+int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes, int cosited,
+                        jpeg_amd_color color, uint8_t *h_pixels, size_t pixel_capacity,
+                        jpeg_amd_frame_info *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,7 +75,21 @@ SIGNATURES = {
     "jpeg_amd_host_rectangular_decomposed": (C.c_int, [_p, _L, _p, _pp]),
     "jpeg_amd_host_planar_fdct": (C.c_int, [_p, _L, _pp, _p, C.c_int, _pp]),
     "jpeg_amd_host_encode": (C.c_int, [_p, _L, _p, C.c_int, _p, C.c_int, _pp]),
+    "jpeg_amd_jpeg_inspect": (C.c_int, [_p, C.c_size_t, _p]),
+    "jpeg_amd_jpeg_decode_spectral": (C.c_int, [_p, C.c_size_t, _pp, _p, _p]),
+    "jpeg_amd_decompress": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_int, _p, C.c_size_t, _p]),
 }
+
+
+class FrameInfo(C.Structure):
+    """struct jpeg_amd_frame_info"""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("precision", C.c_int32), ("ncomponents", C.c_int32),
+        ("process", C.c_int32), ("scale_x", C.c_int32), ("scale_y", C.c_int32),
+        ("id", C.c_int32 * MAX_PLANES), ("factor_x", C.c_int32 * MAX_PLANES), ("factor_y", C.c_int32 * MAX_PLANES),
+        ("units_x", C.c_int32 * MAX_PLANES), ("units_y", C.c_int32 * MAX_PLANES),
+        ("nscans", C.c_int32), ("restart_interval", C.c_int32),
+    ]
 
 _LIB = None
 

@@ -234,6 +234,50 @@ class Spectral:
     def host_planes(self) -> List[np.ndarray]:
         return [p.cpu().numpy() for p in self.planes]
 
+    @classmethod
+    def decompress(cls, ctx: Context, source) -> "Spectral":
+        """Spectral.decompress(stream:) / decompress(path:) -- decode.swift:3728, os.swift:309.
+        source: a path or the file's bytes.  The entropy-coded segments are decoded on the host
+        by the library (csrc/entropy.cpp); the coefficient planes land in HBM."""
+        data = _file_bytes(source)
+        info, planes, quanta = _decode_spectral(data)
+        n = info.ncomponents
+        if info.precision == 8 and n == 1:
+            fmt = "y8"
+        elif info.precision == 8 and n == 3:
+            fmt = "ycc8"
+        else:
+            fmt = ("custom", info.precision, n)
+        layout = Layout(fmt, {info.id[c]: Component((info.factor_x[c], info.factor_y[c]), c) for c in range(n)})
+        return cls.from_host(ctx, (info.width, info.height), layout, planes, [quanta[c] for c in range(n)],
+                             q=list(range(n)))
+
+
+def _file_bytes(source) -> np.ndarray:
+    if isinstance(source, np.ndarray):
+        return np.ascontiguousarray(source, np.uint8)
+    if isinstance(source, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(source), np.uint8)
+    return np.fromfile(source, np.uint8)       # a path
+
+
+def inspect(source) -> _lib.FrameInfo:
+    """Frame geometry of a JPEG file without decoding its scans (jpeg_amd_jpeg_inspect)."""
+    data = _file_bytes(source)
+    info = _lib.FrameInfo()
+    _lib.check(_lib.lib().jpeg_amd_jpeg_inspect(data.ctypes.data, data.size, C.byref(info)), "jpeg_amd_jpeg_inspect")
+    return info
+
+
+def _decode_spectral(data: np.ndarray):
+    info = inspect(data)
+    planes = [np.empty((info.units_y[c], info.units_x[c], 64), np.int16) for c in range(info.ncomponents)]
+    quanta = np.zeros((MAX_PLANES, 64), np.uint16)
+    _lib.check(_lib.lib().jpeg_amd_jpeg_decode_spectral(
+        data.ctypes.data, data.size, _lib.ptr_array([p.ctypes.data for p in planes]), quanta.ctypes.data, None),
+        "jpeg_amd_jpeg_decode_spectral")
+    return info, planes, quanta
+
 
 def _dedupe_q(layout: Layout) -> List[int]:
     """Spectral.set(quanta:) (decode.swift:2510-2543): one table per distinct quanta key,
@@ -327,6 +371,12 @@ class Rectangular:
             self.ctx.handle, self.values.data_ptr(), n, self.layout.count, color.code,
             out.data_ptr()), "jpeg_amd_rectangular_unpack", self.ctx.handle)
         return out.view(-1, 3)
+
+    @classmethod
+    def decompress(cls, ctx: Context, source, cosite: bool = False) -> "Rectangular":
+        """Rectangular.decompress(stream:cosite:) -- decode.swift:4367-4374:
+        Spectral.decompress(...).idct().interleaved(cosite:)."""
+        return Spectral.decompress(ctx, source).idct().interleaved(cosite=cosite)
 
     @classmethod
     def pack(cls, ctx, size, layout, pixels, color=RGB) -> "Rectangular":

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libjpeg_amd.so")
 
-SOURCES = ["kernels_stage.hip", "kernels_fused.hip", "kernels_encode.hip", "capi.hip"]
+SOURCES = ["kernels_stage.hip", "kernels_fused.hip", "kernels_encode.hip", "capi.hip", "entropy.cpp"]
 HEADERS = ["dct.hpp", "kernels.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-command-line-argument"]
@@ -45,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cc = hipcc()
     objs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         cmd = [cc, *FLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

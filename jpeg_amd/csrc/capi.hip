@@ -720,4 +720,38 @@ int jpeg_amd_host_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const uint
     return JPEG_AMD_OK;
 }
 
+// ---- JPEG bytes -> pixels (host entropy decode + the fused device path) ----------------------
+int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes, int cosited,
+                        jpeg_amd_color color, uint8_t *h_pixels, size_t pixel_capacity,
+                        jpeg_amd_frame_info *info_out)
+{
+    JA_TRY(bind(ctx));
+    jpeg_amd_frame_info fi;
+    JA_TRY(jpeg_amd_jpeg_inspect(h_jpeg, nbytes, &fi));
+    if (info_out) *info_out = fi;
+    // JPEG.Common recognises 8-bit images of arity 1 or 3 (jpeg.swift:357-424)
+    if (fi.precision != 8 || (fi.ncomponents != 1 && fi.ncomponents != 3)) return JPEG_AMD_ENOSUP;
+    const size_t need = (size_t)fi.width * fi.height * 3;
+    if (!h_pixels || pixel_capacity < need) return JPEG_AMD_EINVAL;
+
+    std::vector<std::vector<int16_t>> planes((size_t)fi.ncomponents);
+    int16_t *coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int c = 0; c < fi.ncomponents; ++c) {
+        planes[c].resize((size_t)64 * fi.units_x[c] * fi.units_y[c]);
+        coef[c] = planes[c].data();
+    }
+    uint16_t quanta[JPEG_AMD_MAX_PLANES][64];
+    JA_TRY(jpeg_amd_jpeg_decode_spectral(h_jpeg, nbytes, coef, quanta, nullptr));
+
+    jpeg_amd_layout L{};
+    L.width = fi.width; L.height = fi.height; L.precision = 8; L.nplanes = fi.ncomponents;
+    L.scale_x = fi.scale_x; L.scale_y = fi.scale_y;
+    for (int c = 0; c < fi.ncomponents; ++c) {
+        L.factor_x[c] = fi.factor_x[c]; L.factor_y[c] = fi.factor_y[c];
+        L.units_x[c] = fi.units_x[c];   L.units_y[c] = fi.units_y[c];
+        L.qi[c] = c;
+    }
+    return jpeg_amd_host_decode(ctx, &L, coef, &quanta[0][0], fi.ncomponents, cosited, color, h_pixels);
+}
+
 }  // extern "C"

@@ -1,0 +1,466 @@
+// entropy.cpp -- host-side JPEG parsing + Huffman entropy decoding into Spectral planes.
+//
+// SURVEY.md section 8f-1/f-2 ("next" rows): the stage that FEEDS the GPU hot path.  It fills
+// the same containers the reference's JPEG.Context fills (decode.swift:3554-3961): per
+// component int16 [units_y][units_x][64] in zigzag order, plus the quantisation table bound to
+// each component.  Entropy coding stays on the host CPU by design (north_star).
+//
+// Written from ITU-T T.81 (Annex F sequential, Annex G progressive); the reference behaviours
+// that matter for parity of the hot path are mirrored and cited:
+//   - plane geometry units = ceil(size * factor / (8 * scale))        decode.swift:2456-2495
+//   - blocks an interleaved scan addresses beyond `units` are decoded and dropped  :1459-1475
+//   - a component's quantisation table is bound at its first scan (sequential scan or
+//     progressive DC-first scan) from whatever the DQT slot holds then   :3447-3473, 3486-3496
+//   - coefficients are stored quantised, zigzag order                    :1434, 1466
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/jpeg_amd.h"
+
+namespace {
+
+struct Huffman {
+    // 9-bit first-level table: (length << 8) | symbol, 0 = longer than 9 bits
+    uint16_t fast[512];
+    // canonical decode for long codes (T.81 F.2.2.3)
+    int32_t maxcode[18];
+    int32_t valptr[17];
+    int32_t mincode[17];
+    uint8_t symbols[256];
+    bool defined = false;
+
+    bool build(const uint8_t counts[16], const uint8_t *syms, int nsyms)
+    {
+        std::memset(fast, 0, sizeof fast);
+        std::memcpy(symbols, syms, (size_t)nsyms);
+        int code = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            valptr[len] = k;
+            mincode[len] = code;
+            for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
+                if (k >= nsyms) return false;
+                if (len <= 9) {
+                    const int lo = code << (9 - len), hi = lo + (1 << (9 - len));
+                    if (hi > 512) return false;
+                    for (int c = lo; c < hi; ++c) fast[c] = (uint16_t)((len << 8) | syms[k]);
+                }
+            }
+            maxcode[len] = counts[len - 1] ? code - 1 : -1;
+            if (code > (1 << len)) return false;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        defined = true;
+        return true;
+    }
+};
+
+// MSB-first bit reader over one entropy-coded segment with byte stuffing removed on the fly.
+// Past the end of the data it supplies 1-bits (a truncated stream then decodes as padding).
+struct BitReader {
+    const uint8_t *p, *end;
+    uint64_t acc = 0;   // left-aligned bit buffer
+    int nbits = 0;
+    bool hit_marker = false;
+
+    BitReader(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
+
+    inline void refill()
+    {
+        while (nbits <= 56) {
+            uint32_t byte = 0xff;
+            if (!hit_marker && p < end) {
+                byte = *p;
+                if (byte == 0xff) {
+                    if (p + 1 < end && p[1] == 0x00) p += 2;          // stuffed 0xFF
+                    else { hit_marker = true; byte = 0xff; }           // RSTn / next marker: stop
+                } else {
+                    ++p;
+                }
+            }
+            acc |= (uint64_t)byte << (56 - nbits);
+            nbits += 8;
+        }
+    }
+    inline uint32_t peek(int n) { return (uint32_t)(acc >> (64 - n)); }
+    inline void skip(int n) { acc <<= n; nbits -= n; }
+    inline uint32_t get(int n)
+    {
+        if (n == 0) return 0;
+        if (nbits < n) refill();
+        const uint32_t v = peek(n);
+        skip(n);
+        return v;
+    }
+    inline int decode(const Huffman &h)
+    {
+        if (nbits < 16) refill();
+        const uint16_t f = h.fast[peek(9)];
+        if (f) { skip(f >> 8); return f & 0xff; }
+        int code = (int)peek(10), len = 10;
+        while (len <= 16 && code > h.maxcode[len]) { ++len; code = (int)peek(len); }
+        if (len > 16) { skip(16); return -1; }
+        skip(len);
+        return h.symbols[h.valptr[len] + code - h.mincode[len]];
+    }
+    // at a restart boundary: drop the padding bits and position on the byte after RSTn
+    // (refill never reads past a marker, so everything buffered belongs to the old interval)
+    void restart()
+    {
+        acc = 0; nbits = 0;
+        while (p + 1 < end && !(p[0] == 0xff && p[1] >= 0xd0 && p[1] <= 0xd7)) ++p;
+        if (p + 1 < end) p += 2;
+        hit_marker = false;
+    }
+};
+
+inline int extend(int v, int s) { return (s == 0 || v >= (1 << (s - 1))) ? v : v - (1 << s) + 1; }  // T.81 F.2.2.1
+
+struct Component {
+    int id = 0, fx = 1, fy = 1, tq = 0;
+    int ux = 0, uy = 0;
+    int16_t *coef = nullptr;
+    bool bound = false;
+};
+
+struct Decoder {
+    const uint8_t *data;
+    size_t n;
+    jpeg_amd_frame_info info{};
+    std::vector<Component> comps;
+    uint16_t qslots[4][64];
+    bool qdefined[4] = {false, false, false, false};
+    Huffman dc[4], ac[4];
+    int restart_interval = 0;
+    int nscans = 0;
+
+    static int units(int size, int stride) { return size / stride + (size % stride != 0 ? 1 : 0); }
+
+    // ---- marker segments ----
+    int parse_dqt(const uint8_t *s, size_t len)
+    {
+        size_t i = 0;
+        while (i < len) {
+            const int pq = s[i] >> 4, tq = s[i] & 15;
+            ++i;
+            if (tq > 3 || pq > 1 || i + (pq ? 128 : 64) > len) return JPEG_AMD_EINVAL;
+            for (int z = 0; z < 64; ++z) {
+                qslots[tq][z] = pq ? (uint16_t)((s[i] << 8) | s[i + 1]) : s[i];   // file order is zigzag
+                i += pq ? 2 : 1;
+            }
+            qdefined[tq] = true;
+        }
+        return JPEG_AMD_OK;
+    }
+    int parse_dht(const uint8_t *s, size_t len)
+    {
+        size_t i = 0;
+        while (i < len) {
+            if (i + 17 > len) return JPEG_AMD_EINVAL;
+            const int tc = s[i] >> 4, th = s[i] & 15;
+            int total = 0;
+            for (int k = 0; k < 16; ++k) total += s[i + 1 + k];
+            if (tc > 1 || th > 3 || total > 256 || i + 17 + (size_t)total > len) return JPEG_AMD_EINVAL;
+            if (!(tc ? ac[th] : dc[th]).build(s + i + 1, s + i + 17, total)) return JPEG_AMD_EINVAL;
+            i += 17 + (size_t)total;
+        }
+        return JPEG_AMD_OK;
+    }
+    int parse_sof(int marker, const uint8_t *s, size_t len)
+    {
+        if (len < 6) return JPEG_AMD_EINVAL;
+        info.process = marker == 0xc0 ? 0 : marker == 0xc1 ? 1 : 2;
+        info.precision = s[0];
+        info.height = (s[1] << 8) | s[2];
+        info.width = (s[3] << 8) | s[4];
+        const int nc = s[5];
+        if (nc < 1 || nc > JPEG_AMD_MAX_PLANES || len < 6 + 3 * (size_t)nc) return JPEG_AMD_ENOSUP;
+        if (info.width <= 0 || info.height <= 0) return JPEG_AMD_ENOSUP;   // DNL-defined heights: not supported
+        info.ncomponents = nc;
+        comps.assign((size_t)nc, Component());
+        int sx = 0, sy = 0;
+        for (int c = 0; c < nc; ++c) {
+            comps[c].id = s[6 + 3 * c];
+            comps[c].fx = s[7 + 3 * c] >> 4;
+            comps[c].fy = s[7 + 3 * c] & 15;
+            comps[c].tq = s[8 + 3 * c];
+            if (comps[c].fx < 1 || comps[c].fy < 1 || comps[c].tq > 3) return JPEG_AMD_EINVAL;
+            if (comps[c].fx > sx) sx = comps[c].fx;
+            if (comps[c].fy > sy) sy = comps[c].fy;
+        }
+        info.scale_x = sx; info.scale_y = sy;
+        for (int c = 0; c < nc; ++c) {
+            comps[c].ux = units(info.width * comps[c].fx, 8 * sx);
+            comps[c].uy = units(info.height * comps[c].fy, 8 * sy);
+            info.id[c] = comps[c].id;
+            info.factor_x[c] = comps[c].fx; info.factor_y[c] = comps[c].fy;
+            info.units_x[c] = comps[c].ux;  info.units_y[c] = comps[c].uy;
+        }
+        return JPEG_AMD_OK;
+    }
+
+    // ---- one scan ----
+    struct ScanComp { Component *c; int td, ta; };
+
+    int decode_scan(const uint8_t *hdr, size_t hlen, const uint8_t *ecs, const uint8_t *end, uint16_t (*quanta_out)[64])
+    {
+        if (hlen < 1) return JPEG_AMD_EINVAL;
+        const int ns = hdr[0];
+        if (ns < 1 || ns > 4 || hlen < 4 + 2 * (size_t)ns) return JPEG_AMD_EINVAL;
+        ScanComp sc[4];
+        for (int j = 0; j < ns; ++j) {
+            const int cid = hdr[1 + 2 * j], tt = hdr[2 + 2 * j];
+            Component *c = nullptr;
+            for (Component &x : comps) if (x.id == cid) c = &x;
+            if (!c) return JPEG_AMD_EINVAL;
+            sc[j] = {c, tt >> 4, tt & 15};
+            if (sc[j].td > 3 || sc[j].ta > 3) return JPEG_AMD_EINVAL;
+        }
+        const int ss = hdr[1 + 2 * ns], se = hdr[2 + 2 * ns], ah = hdr[3 + 2 * ns] >> 4, al = hdr[3 + 2 * ns] & 15;
+        const bool progressive = info.process == 2;
+        if (se > 63 || ss > se) return JPEG_AMD_EINVAL;
+        if (progressive && ss > 0 && ns != 1) return JPEG_AMD_EINVAL;
+        if (!progressive && (ss != 0 || se != 63 || ah != 0 || al != 0)) {
+            // tolerate odd headers of sequential scans the way libjpeg does: treat as full band
+        }
+        // bind quantisation tables at the component's first scan
+        if (ah == 0 && ss == 0) {
+            for (int j = 0; j < ns; ++j) {
+                Component *c = sc[j].c;
+                if (!qdefined[c->tq]) return JPEG_AMD_EINVAL;
+                if (quanta_out) std::memcpy(quanta_out[c - comps.data()], qslots[c->tq], 128);
+                c->bound = true;
+            }
+        }
+        if (!comps[0].coef) return JPEG_AMD_OK;   // inspect-only pass
+
+        // MCU geometry
+        int mcux, mcuy;
+        struct Slot { Component *c; int td, ta, bx, by; };
+        Slot slots[16];
+        int nslots = 0;
+        if (ns > 1) {
+            mcux = units(info.width, 8 * info.scale_x);
+            mcuy = units(info.height, 8 * info.scale_y);
+            for (int j = 0; j < ns; ++j)
+                for (int by = 0; by < sc[j].c->fy; ++by)
+                    for (int bx = 0; bx < sc[j].c->fx; ++bx) {
+                        if (nslots >= 16) return JPEG_AMD_ENOSUP;
+                        slots[nslots++] = {sc[j].c, sc[j].td, sc[j].ta, bx, by};
+                    }
+        } else {
+            mcux = sc[0].c->ux; mcuy = sc[0].c->uy;
+            slots[nslots++] = {sc[0].c, sc[0].td, sc[0].ta, 0, 0};
+        }
+        const long total = (long)mcux * mcuy;
+        const long ri = restart_interval ? restart_interval : total;
+
+        BitReader br(ecs, end);
+        int pred[4] = {0, 0, 0, 0};
+        int eobrun = 0;
+        int16_t dummy[64];
+        for (long mcu = 0; mcu < total; ++mcu) {
+            if (mcu && mcu % ri == 0) {
+                br.restart();
+                pred[0] = pred[1] = pred[2] = pred[3] = 0;
+                eobrun = 0;
+            }
+            const int my = (int)(mcu / mcux), mx = (int)(mcu - (long)my * mcux);
+            for (int si = 0; si < nslots; ++si) {
+                const Slot &sl = slots[si];
+                Component *c = sl.c;
+                const int x = ns > 1 ? mx * c->fx + sl.bx : mx, y = ns > 1 ? my * c->fy + sl.by : my;
+                const bool inside = x < c->ux && y < c->uy;
+                int16_t *blk = inside ? c->coef + (size_t)64 * ((size_t)c->ux * y + x) : dummy;
+                const int ci = (int)(c - comps.data());
+                if (!inside) std::memset(dummy, 0, sizeof dummy);
+                if (!progressive) {
+                    // sequential: T.81 F.2.2
+                    if (!dc[sl.td].defined || !ac[sl.ta].defined) return JPEG_AMD_EINVAL;
+                    const int t = br.decode(dc[sl.td]);
+                    if (t < 0 || t > 16) return JPEG_AMD_EINVAL;
+                    pred[ci] += extend((int)br.get(t), t);
+                    blk[0] = (int16_t)pred[ci];
+                    const Huffman &h = ac[sl.ta];
+                    for (int k = 1; k < 64;) {
+                        const int rs = br.decode(h);
+                        if (rs < 0) return JPEG_AMD_EINVAL;
+                        const int r = rs >> 4, s = rs & 15;
+                        if (s == 0) {
+                            if (r == 15) { k += 16; continue; }
+                            break;
+                        }
+                        k += r;
+                        const int v = extend((int)br.get(s), s);
+                        if (k < 64) blk[k] = (int16_t)v;
+                        ++k;
+                    }
+                } else if (ss == 0) {
+                    if (ah == 0) {   // DC first: T.81 G.1.2.1
+                        if (!dc[sl.td].defined) return JPEG_AMD_EINVAL;
+                        const int t = br.decode(dc[sl.td]);
+                        if (t < 0 || t > 16) return JPEG_AMD_EINVAL;
+                        pred[ci] += extend((int)br.get(t), t);
+                        blk[0] = (int16_t)(pred[ci] * (1 << al));
+                    } else if (br.get(1)) {
+                        blk[0] = (int16_t)(blk[0] | (1 << al));
+                    }
+                } else if (ah == 0) {   // AC first: T.81 G.1.2.2
+                    if (eobrun > 0) { --eobrun; continue; }
+                    if (!ac[sl.ta].defined) return JPEG_AMD_EINVAL;
+                    const Huffman &h = ac[sl.ta];
+                    for (int k = ss; k <= se;) {
+                        const int rs = br.decode(h);
+                        if (rs < 0) return JPEG_AMD_EINVAL;
+                        const int r = rs >> 4, s = rs & 15;
+                        if (s == 0) {
+                            if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += (int)br.get(r); break; }
+                            k += 16;
+                            continue;
+                        }
+                        k += r;
+                        const int v = extend((int)br.get(s), s);
+                        if (k <= se) blk[k] = (int16_t)(v * (1 << al));
+                        ++k;
+                    }
+                } else {   // AC refinement: T.81 G.1.2.3
+                    if (!ac[sl.ta].defined) return JPEG_AMD_EINVAL;
+                    const Huffman &h = ac[sl.ta];
+                    const int p1 = 1 << al, m1 = -(1 << al);
+                    int k = ss;
+                    auto refine = [&](int16_t &cf) {
+                        if (br.get(1) && (cf & p1) == 0) cf = (int16_t)(cf >= 0 ? cf + p1 : cf + m1);
+                    };
+                    if (eobrun == 0) {
+                        for (; k <= se; ++k) {
+                            const int rs = br.decode(h);
+                            if (rs < 0) return JPEG_AMD_EINVAL;
+                            int r = rs >> 4;
+                            const int s = rs & 15;
+                            int val = 0;
+                            if (s) {
+                                val = br.get(1) ? p1 : m1;
+                            } else if (r < 15) {
+                                eobrun = 1 << r;
+                                if (r) eobrun += (int)br.get(r);
+                                break;
+                            }
+                            for (; k <= se; ++k) {
+                                if (blk[k] != 0) refine(blk[k]);
+                                else if (--r < 0) break;
+                            }
+                            if (s && k <= se) blk[k] = (int16_t)val;
+                        }
+                    }
+                    if (eobrun > 0) {
+                        for (; k <= se; ++k)
+                            if (blk[k] != 0) refine(blk[k]);
+                        --eobrun;
+                    }
+                }
+            }
+        }
+        return JPEG_AMD_OK;
+    }
+
+    // Walk the whole file.  coef == nullptr: headers only (fills info, counts scans).
+    int run(int16_t *const coef[], uint16_t (*quanta_out)[64])
+    {
+        if (n < 4 || data[0] != 0xff || data[1] != 0xd8) return JPEG_AMD_EINVAL;
+        size_t pos = 2;
+        bool have_frame = false;
+        while (pos + 1 < n) {
+            if (data[pos] != 0xff) return JPEG_AMD_EINVAL;
+            while (pos + 1 < n && data[pos + 1] == 0xff) ++pos;
+            if (pos + 1 >= n) break;
+            const int marker = data[pos + 1];
+            pos += 2;
+            if (marker == 0xd9) break;                                   // EOI
+            if (marker == 0x01 || (marker >= 0xd0 && marker <= 0xd7)) continue;
+            if (pos + 2 > n) return JPEG_AMD_EINVAL;
+            const size_t seglen = ((size_t)data[pos] << 8) | data[pos + 1];
+            if (seglen < 2 || pos + seglen > n) return JPEG_AMD_EINVAL;
+            const uint8_t *seg = data + pos + 2;
+            const size_t len = seglen - 2;
+            pos += seglen;
+            int st = JPEG_AMD_OK;
+            switch (marker) {
+                case 0xdb: st = parse_dqt(seg, len); break;
+                case 0xc4: st = parse_dht(seg, len); break;
+                case 0xc0: case 0xc1: case 0xc2:
+                    if (have_frame) return JPEG_AMD_ENOSUP;
+                    st = parse_sof(marker, seg, len);
+                    if (st == JPEG_AMD_OK) {
+                        have_frame = true;
+                        if (coef)
+                            for (int c = 0; c < info.ncomponents; ++c) {
+                                if (!coef[c]) return JPEG_AMD_EINVAL;
+                                comps[c].coef = coef[c];
+                                std::memset(coef[c], 0, (size_t)128 * comps[c].ux * comps[c].uy);
+                            }
+                    }
+                    break;
+                case 0xc3: case 0xc5: case 0xc6: case 0xc7: case 0xc9: case 0xca: case 0xcb:
+                case 0xcd: case 0xce: case 0xcf:
+                    return JPEG_AMD_ENOSUP;                                // lossless / hierarchical / arithmetic
+                case 0xdd:
+                    if (len < 2) return JPEG_AMD_EINVAL;
+                    restart_interval = (seg[0] << 8) | seg[1];
+                    break;
+                case 0xda: {
+                    if (!have_frame) return JPEG_AMD_EINVAL;
+                    // entropy-coded data runs to the next marker that is not RSTn / stuffing
+                    size_t e = pos;
+                    while (e + 1 < n) {
+                        if (data[e] != 0xff) { ++e; continue; }
+                        const int m = data[e + 1];
+                        if (m == 0x00 || (m >= 0xd0 && m <= 0xd7)) { e += 2; continue; }
+                        if (m == 0xff) { ++e; continue; }
+                        break;
+                    }
+                    if (e + 1 >= n) e = n;
+                    st = decode_scan(seg, len, data + pos, data + e, quanta_out);
+                    ++nscans;
+                    pos = e;
+                    break;
+                }
+                default: break;                                           // APPn, COM, DNL, ...: skipped
+            }
+            if (st != JPEG_AMD_OK) return st;
+        }
+        if (!have_frame) return JPEG_AMD_EINVAL;
+        info.nscans = nscans;
+        info.restart_interval = restart_interval;
+        return JPEG_AMD_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int jpeg_amd_jpeg_inspect(const uint8_t *data, size_t nbytes, jpeg_amd_frame_info *info)
+{
+    if (!data || !info) return JPEG_AMD_EINVAL;
+    Decoder d{data, nbytes};
+    const int st = d.run(nullptr, nullptr);
+    if (st != JPEG_AMD_OK) return st;
+    *info = d.info;
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_jpeg_decode_spectral(const uint8_t *data, size_t nbytes, int16_t *const h_coef[],
+                                  uint16_t h_quanta[][64], jpeg_amd_frame_info *info)
+{
+    if (!data || !h_coef || !h_quanta) return JPEG_AMD_EINVAL;
+    Decoder d{data, nbytes};
+    const int st = d.run(h_coef, h_quanta);
+    if (st != JPEG_AMD_OK) return st;
+    for (const Component &c : d.comps)
+        if (!c.bound) return JPEG_AMD_EINVAL;   // a component no scan ever touched
+    if (info) *info = d.info;
+    return JPEG_AMD_OK;
+}
+
+}  // extern "C"

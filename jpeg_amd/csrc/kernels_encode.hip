@@ -44,15 +44,6 @@ struct EncArgs {
     int tiles_x;
 };
 
-// natural index (8h + k) of zigzag slot z (inverse of zigzag_of), usable at compile time
-__host__ __device__ constexpr int natural_of(int z)
-{
-    for (int h = 0; h < 8; ++h)
-        for (int k = 0; k < 8; ++k)
-            if (zigzag_of(k, h) == z) return 8 * h + k;
-    return 0;
-}
-
 template <int N>
 __device__ __forceinline__ float ubyte(uint32_t v)
 {

@@ -34,7 +34,6 @@ constexpr int kThreads = 256;
 // channel values x = y + m c (see k_luma_fused and tests/test_colour_rounding.py)
 constexpr float kTruncBias = -0.5f + 0.0009765625f;
 constexpr int TBX = 32;  // luma blocks per tile row   (tile = 256 x 64 px)
-constexpr int TBY = 8;   // luma blocks per tile column
 
 // ---------------------------------------------------------------------------------------
 // K1: chroma planes -> uint8 samples.  blockIdx.z selects the plane (same geometry).
@@ -185,7 +184,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     constexpr int PITCH = (CW + 2 * HX) / 4;             // dwords per LDS row
     constexpr int ROWS = CR + 2 * HY;
     constexpr int PLANE = CHROMA ? ROWS * PITCH : 1;
-    constexpr int NF = CHROMA ? (2 * PLANE + 63) / 64 : 1;  // fill dwords per lane
     constexpr int SEG_DW = TBX * 6;                      // one 32-block row segment: 768 B
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][2 * SEG_DW]; // one pixel row x 2 block rows

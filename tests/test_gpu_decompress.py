@@ -1,0 +1,70 @@
+"""jpeg_amd_decompress: file bytes -> pixels in one call (host entropy decoder
+feeding the device path).  Must reproduce the reference's regression golds
+(tests/regression/gold, examples/decode-*) byte for byte."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _golden as G
+from jpeg_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import jpeg_amd as J
+    return J.Context()
+
+
+def _decompress(ctx, path, color):
+    lib = _lib.lib()
+    data = np.fromfile(path, np.uint8)
+    info = _lib.FrameInfo()
+    assert lib.jpeg_amd_jpeg_inspect(data.ctypes.data, data.size, C.byref(info)) == 0
+    out = np.zeros(info.width * info.height * 3, np.uint8)
+    st = lib.jpeg_amd_decompress(ctx.handle, data.ctypes.data, data.size, 0, color.code, out.ctypes.data, out.size, C.byref(info))
+    assert st == 0, st
+    return out
+
+
+@pytest.mark.parametrize("name", G.decode_names(gold_only=True))
+def test_decompress_matches_reference_gold(ctx, name):
+    import jpeg_amd as J
+    e = G.entry(name)
+    for key, color in (("rgb_sha256", J.RGB), ("ycc_sha256", J.YCbCr)):
+        if key in e["gold"]:
+            assert G.sha(_decompress(ctx, G.path(e["file"]), color)) == e["gold"][key]
+
+
+@pytest.mark.parametrize("name", [n for n in G.decode_names() if "restart" in n])
+def test_decompress_restart_files_match_oracle(ctx, name):
+    import jpeg_amd as J
+    from oracle import oracle as O
+    img = G.image(name)
+    _, rect = O.decode(img.planes, img.quanta, img.factors, (img.width, img.height))
+    want = O.unpack_rgb8(rect, len(img.components))
+    got = _decompress(ctx, G.path(G.entry(name)["file"]), J.RGB)
+    assert (got.reshape(want.shape) == want).all()
+
+
+def test_decompress_rejects_small_output_buffer(ctx):
+    import jpeg_amd as J
+    lib = _lib.lib()
+    data = np.fromfile(G.path(G.entry("color-sequential-1.jpg")["file"]), np.uint8)
+    out = np.zeros(16, np.uint8)
+    st = lib.jpeg_amd_decompress(ctx.handle, data.ctypes.data, data.size, 0, J.RGB.code, out.ctypes.data, out.size, None)
+    assert st == _lib.EINVAL
+
+
+@pytest.mark.parametrize("name", ["color-progressive-2.jpg", "grayscale-sequential-1.jpg", "karlie-kwk-2019.jpg"])
+def test_python_mirror_decompress(ctx, name):
+    """Spectral.decompress / Rectangular.decompress (decode.swift:3728, 4367) from a path and from bytes."""
+    import jpeg_amd as J
+    e = G.entry(name)
+    path = G.path(e["file"])
+    rgb = J.Rectangular.decompress(ctx, path).unpack(J.RGB).cpu().numpy()
+    assert G.sha(rgb) == e["gold"]["rgb_sha256"]
+    fused = J.Spectral.decompress(ctx, open(path, "rb").read()).decode(J.RGB).cpu().numpy()
+    assert (fused == rgb).all()

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjpeg_amd.so")
+# JPEG_AMD_LIBRARY points at an alternative build of the same library (tools/ experiments)
+LIB_PATH = os.environ.get("JPEG_AMD_LIBRARY") or os.path.join(HERE, "libjpeg_amd.so")
 MAX_PLANES = 4
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV, ENOSUP = 0, -1, -2, -3, -4, -5

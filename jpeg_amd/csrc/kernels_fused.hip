@@ -160,18 +160,31 @@ __device__ __forceinline__ void lerp_row_2x(const float (&p)[6], float (&o)[8])
 // shorter, because loads retire in order.)
 __device__ __forceinline__ void lds_dma16(const void *g, uint32_t lds)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(lds) : "memory");
 }
 // Same with a scalar 64-bit base + per-lane 32-bit byte offset (no vector address arithmetic).
 __device__ __forceinline__ void lds_dma16_s(uint64_t sbase, uint32_t voff, uint32_t lds)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
 }
 // 4 bytes per lane: lane l's dword lands at LDS byte address lds + 4 l.
 __device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32_t lds)
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
 }
+
+#ifdef JA_PHASE_PROFILE
+// development aid (tools/phase_profile.py): wall cycles each wave spends per phase of a strip
+__device__ unsigned long long g_phase_cycles[4096 * 8];
+#define JA_PHASE(i)                                                       \
+    {                                                                     \
+        const unsigned long long t_now = __builtin_readcyclecounter();    \
+        phase_acc[i] += t_now - t_prev;                                   \
+        t_prev = t_now;                                                   \
+    }
+#else
+#define JA_PHASE(i)
+#endif
 
 template <int SX, int SY, int MODE, bool CHROMA, bool FAST>
 __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
@@ -246,6 +259,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     if (s >= a.total_tiles) return;
     dma_strip(s, lane0);
     int img_of_table = -1;
+    int stores_behind_dma = 0;  // wave-uniform
+#ifdef JA_PHASE_PROFILE
+    unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
 
     for (; s < a.total_tiles; s += nwaves) {
         // Launder the lane id once per strip: everything below that depends only on the lane is
@@ -263,8 +281,14 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             img_of_table = img;
         }
 
-        // ---- this strip's coefficients: wait for the DMA, read 8 x 16 B (swizzled) ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- this strip's coefficients: wait for the DMA, read 8 x 16 B (swizzled).  VM
+        //      operations retire in issue order and the DMA was issued BEFORE the previous
+        //      strip's pixel stores: when that strip took the branch-free store path (exactly
+        //      2 store instructions per pixel row) only the DMA has to be waited for, not the
+        //      16 stores behind it. ----
+        if (stores_behind_dma == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        JA_PHASE(0)
         uint32_t w[32];
         {
             const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
@@ -298,10 +322,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
 
         // ---- luma: dequantise + IDCT, clamp + truncate (decode.swift:4121-4122), kept as
         //      integer-valued floats for the colour matrix ----
+        JA_PHASE(1)
         float yv[64];
+#ifdef JA_X_NOIDCT  // experiment: how long is a strip without the IDCT arithmetic?
+#pragma unroll
+        for (int i = 0; i < 64; ++i) yv[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff);
+#else
         idct_block(w, sq, 128.5f, yv);
 #pragma unroll
         for (int i = 0; i < 64; ++i) yv[i] = floorf(__builtin_amdgcn_fmed3f(yv[i], 0.0f, 255.0f));
+#endif
 
         // Pin the IDCT HERE: LLVM otherwise sinks it below the waits / DMA (its results are first
         // used in the colour phase) and the wave would park on the chroma rows before doing any
@@ -309,6 +339,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
 #pragma unroll
         for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(yv[i]));
         __builtin_amdgcn_sched_barrier(0);
+        JA_PHASE(2)
 
         // ---- the chroma rows have landed (they are the only VM operations in flight) ----
         if constexpr (CHROMA) {
@@ -328,6 +359,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane);
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
+        JA_PHASE(3)
 
         // ---- chroma rows, produced just in time from the LDS tile ----
         constexpr float inv = 1.0f / (float)((SX == 2 ? 4 : 1) * (SY == 2 ? 4 : 1));
@@ -369,6 +401,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = 8u * pitch + 16u * j1;
         const bool full = 16 * syi + 16 <= a.H && tile_px == TBX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
+        stores_behind_dma = (FAST && full) ? 16 : 0;
+        JA_PHASE(4)
 
 #pragma unroll
         for (int y = 0; y < 8; ++y) {  // pixel row y of both block rows
@@ -411,10 +445,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                         // truncation for EVERY (y, c) in [0,255] x [-128,127]: the products
                         // 1.402 c / 1.772 c never come closer than 0.004 to an integer
                         // (verified exhaustively by tests/test_colour_rounding.py).
+                        // Nor do they come close enough for the rounding of the product to
+                        // matter, so R and B take one FMA each (same test, fused variant).
                         const float yb = yy + kTruncBias;
-                        c0 = yb + 1.40200f * pr;
-                        c1 = floorf((yy + -0.34414f * pb) + -0.71414f * pr);
-                        c2 = yb + 1.77200f * pb;
+                        c0 = __builtin_fmaf(1.40200f, pr, yb);
+                        // G: floor(fma(m_cr, cr, fma(m_cb, cb, y))) equals the reference's
+                        // trunc((y + m_cb cb) + m_cr cr) for every (y, cb, cr) -- all 2^24
+                        // triples checked in tests/test_colour_rounding.py (the other fused
+                        // association is NOT exact).
+                        c1 = floorf(__builtin_fmaf(-0.71414f, pr, __builtin_fmaf(-0.34414f, pb, yy)));
+                        c2 = __builtin_fmaf(1.77200f, pb, yb);
                     } else {
                         c0 = c1 = c2 = yy;  // cb = cr = 128: every matrix term is +-0
                     }
@@ -439,13 +479,18 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                 const uint4 v1 = *reinterpret_cast<const uint4 *>(stage_w + 4 * (64 + (lane & 31)));
                 auto put = [&](uint8_t *o, const uint4 &v, int j) {
                     if constexpr (FAST) {
-                        *reinterpret_cast<uint4 *>(o) = v;
+                        // streaming output, never re-read: non-temporal stores keep it from displacing
+                        // the chroma planes in L2 / Infinity Cache (-6 % step time)
+                        store_nt16(o, v);
                     } else {
                         const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
                         for (int k = 0; k < 16; ++k)
                             if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
                     }
                 };
+#ifdef JA_X_NOSTORE  // experiment: everything but the global stores
+                if (a.W < 0)
+#endif
                 if (FAST && full) {
                     put(rowp + voff0, v0, j0);
                     if (lane < 32) put(rowp + voff1, v1, j1);
@@ -455,7 +500,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                 }
             }
         }
+        JA_PHASE(5)
     }
+#ifdef JA_PHASE_PROFILE
+    if (lane0 == 0 && blockIdx.x * NW + wave < 4096)
+        for (int i = 0; i < 8; ++i) g_phase_cycles[(blockIdx.x * NW + wave) * 8 + i] = phase_acc[i];
+#endif
 }
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
@@ -474,6 +524,13 @@ hipError_t launch_luma(hipStream_t stream, dim3 grid, const LumaArgs &a, int sx,
 }
 
 }  // namespace
+
+#ifdef JA_PHASE_PROFILE
+extern "C" int jpeg_amd_debug_phase_cycles(unsigned long long *h_out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_phase_cycles), n * sizeof(unsigned long long));
+}
+#endif
 
 bool fused_decode_supported(const jpeg_amd_layout &L, bool cosited)
 {

@@ -37,6 +37,20 @@ def test_red_and_blue_every_input():
         assert np.array_equal(want, got)
 
 
+def test_red_and_blue_fused_multiply_add_every_input():
+    """The kernel evaluates sat_rne(fma(m, c, y + kTruncBias)): one rounding of the exact
+    m*c + (y + bias).  float64 holds that sum exactly (24-bit x 8-bit product, 19-bit addend)."""
+    y = np.arange(256, dtype=f32)[:, None]
+    c = np.arange(-128, 128, dtype=f32)[None, :]
+    yb = (y + BIAS).astype(f32)
+    for m in (f32(1.40200), f32(1.77200)):
+        want = _ref((y + (m * c).astype(f32)).astype(f32))
+        exact = np.float64(m) * c.astype(np.float64) + yb.astype(np.float64)
+        assert np.all(exact - yb.astype(np.float64) == np.float64(m) * c.astype(np.float64))   # no f64 rounding
+        got = _hw(exact.astype(f32))
+        assert np.array_equal(want, got)
+
+
 def test_green_needs_the_floor():
     y = np.arange(256, dtype=f32)[:, None, None]
     pb = np.arange(-128, 128, dtype=f32)[None, :, None]
@@ -47,3 +61,22 @@ def test_green_needs_the_floor():
     z = (((y + BIAS).astype(f32) + q1).astype(f32) + q2).astype(f32)
     assert (_ref(x) != _hw(z)).any()                  # the shortcut would be wrong here ...
     assert np.array_equal(_ref(x), _hw(np.floor(x)))  # ... floor + saturating convert is exact
+
+
+def _fma(p, q, r):
+    """binary32 fma of a constant p, small integers q and a binary32 r: the float64 value
+    p*q + r is exact here (< 40 significant bits), so one cast rounds once, like the hardware."""
+    return (np.float64(p) * q.astype(np.float64) + r.astype(np.float64)).astype(f32)
+
+
+def test_green_two_fused_multiply_adds_every_input():
+    y = np.arange(256, dtype=f32)[:, None, None]
+    pb = np.arange(-128, 128, dtype=f32)[None, :, None]
+    pr = np.arange(-128, 128, dtype=f32)[None, None, :]
+    a, b = f32(-0.34414), f32(-0.71414)
+    x = ((y + (a * pb).astype(f32)).astype(f32) + (b * pr).astype(f32)).astype(f32)
+    want = _ref(x)
+    got = _hw(np.floor(_fma(b, pr, _fma(a, pb, y + 0 * pb))))
+    assert np.array_equal(want, got)                  # the kernel's form: exact on all 2^24 triples
+    other = _hw(np.floor(_fma(a, pb, _fma(b, pr, y + 0 * pr))))
+    assert (other != want).any()                      # the other association is not

@@ -602,6 +602,9 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
 #ifdef JA_X_SKIPK2
     return hipSuccess;
 #endif
+    // grid == resident capacity.  (Sizing it so that every wave gets the same number of strips --
+    // fewer waves, no thin last round -- measured 4 % slower; 2 instead of 3 workgroups per CU
+    // is 3.5 % slower.)
     const int wgs = (la.total_tiles + 3) / 4;
     const dim3 grid(wgs < 768 ? wgs : 768);
     const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;

@@ -510,15 +510,37 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
 
-template <int MODE, bool FAST>
-hipError_t launch_luma(hipStream_t stream, dim3 grid, const LumaArgs &a, int sx, int sy, bool chroma)
+// Persistent grid = what is resident at once: workgroups per CU (LDS- and VGPR-bound, differs per
+// instantiation: 3 for 4:2:0 and grey, 2 for the variants with a full-width chroma tile) x CUs.
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST>
+int resident_workgroups()
 {
-#define JA_K(SX_, SY_, CH_) hipLaunchKernelGGL((k_luma_fused<SX_, SY_, MODE, CH_, FAST>), grid, dim3(kThreads), 0, stream, a)
-    if (!chroma) JA_K(1, 1, false);
-    else if (sx == 2 && sy == 2) JA_K(2, 2, true);
-    else if (sx == 2 && sy == 1) JA_K(2, 1, true);
-    else if (sx == 1 && sy == 2) JA_K(1, 2, true);
-    else JA_K(1, 1, true);
+    static int cached = 0;  // one per instantiation
+    if (cached == 0) {
+        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST>;
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached = per_cu * cus;
+    }
+    return cached;
+}
+
+template <int MODE, bool FAST>
+hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, int sy, bool chroma)
+{
+#define JA_K(SX_, SY_, CH_)                                                          \
+    {                                                                                \
+        auto k = k_luma_fused<SX_, SY_, MODE, CH_, FAST>;                            \
+        const int cap = resident_workgroups<SX_, SY_, MODE, CH_, FAST>();            \
+        hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a); \
+    }
+    if (!chroma) JA_K(1, 1, false)
+    else if (sx == 2 && sy == 2) JA_K(2, 2, true)
+    else if (sx == 2 && sy == 1) JA_K(2, 1, true)
+    else if (sx == 1 && sy == 2) JA_K(1, 2, true)
+    else JA_K(1, 1, true)
 #undef JA_K
     return hipGetLastError();
 }
@@ -606,15 +628,14 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     // fewer waves, no thin last round -- measured 4 % slower; 2 instead of 3 workgroups per CU
     // is 3.5 % slower.)
     const int wgs = (la.total_tiles + 3) / 4;
-    const dim3 grid(wgs < 768 ? wgs : 768);
     const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;
     const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
     if (fast)
-        return rgb ? launch_luma<1, true>(stream, grid, la, sx, sy, chroma)
-                   : launch_luma<0, true>(stream, grid, la, sx, sy, chroma);
-    return rgb ? launch_luma<1, false>(stream, grid, la, sx, sy, chroma)
-               : launch_luma<0, false>(stream, grid, la, sx, sy, chroma);
+        return rgb ? launch_luma<1, true>(stream, wgs, la, sx, sy, chroma)
+                   : launch_luma<0, true>(stream, wgs, la, sx, sy, chroma);
+    return rgb ? launch_luma<1, false>(stream, wgs, la, sx, sy, chroma)
+               : launch_luma<0, false>(stream, wgs, la, sx, sy, chroma);
 }
 
 }  // namespace jpeg_amd

@@ -234,6 +234,43 @@ class Spectral:
     def host_planes(self) -> List[np.ndarray]:
         return [p.cpu().numpy() for p in self.planes]
 
+    def compress(self, scans, process: str = "baseline", jfif=None, path=None) -> bytes:
+        """Spectral.compress(stream:) / compress(path:) -- encode.swift:1918-1972, os.swift:330.
+        scans: the layout's scan progression, one list of (plane index, dc selector, ac selector)
+        per sequential scan.  The coefficient planes come back to the host and are entropy-coded
+        there (csrc/entropy_encode.cpp).  Returns the file's bytes (and writes `path`)."""
+        info = _lib.FrameInfo()
+        info.width, info.height = self.size
+        info.precision, info.ncomponents = self.layout.precision, self.layout.count
+        info.process = {"baseline": 0, "extended": 1, "progressive": 2}[process]
+        info.scale_x, info.scale_y = self.layout.scale
+        keys = []
+        for p, (key, comp) in enumerate(zip(self.layout.recognized, self.layout.planes)):
+            info.id[p] = int(key)
+            info.factor_x[p], info.factor_y[p] = comp.factor
+            info.units_x[p], info.units_y[p] = self.units[p]
+            keys.append(comp.qi)
+        host = [np.ascontiguousarray(p.cpu().numpy()) for p in self.planes]
+        # self.quanta[self.q[p]] is plane p's table; give every distinct quanta key one table
+        tkeys = sorted(set(keys))
+        tables = np.stack([self.quanta[self.q[keys.index(k)]] for k in tkeys]).astype(np.uint16)
+        qkey = (C.c_int32 * len(keys))(*keys)
+        tk = (C.c_int32 * len(tkeys))(*tkeys)
+        sarr = _scan_array(scans)
+        j = _jfif(jfif)
+        n = C.c_size_t()
+        args = [C.byref(info), qkey, _lib.ptr_array([h.ctypes.data for h in host]), tables.ctypes.data, tk, len(tkeys),
+                sarr, len(scans), C.byref(j) if j is not None else None]
+        _lib.check(_lib.lib().jpeg_amd_jpeg_encode_spectral(*args, None, 0, C.byref(n)), "jpeg_amd_jpeg_encode_spectral")
+        out = np.empty(n.value, np.uint8)
+        _lib.check(_lib.lib().jpeg_amd_jpeg_encode_spectral(*args, out.ctypes.data, out.size, C.byref(n)),
+                   "jpeg_amd_jpeg_encode_spectral")
+        data = out.tobytes()
+        if path is not None:
+            with open(path, "wb") as f:
+                f.write(data)
+        return data
+
     @classmethod
     def decompress(cls, ctx: Context, source) -> "Spectral":
         """Spectral.decompress(stream:) / decompress(path:) -- decode.swift:3728, os.swift:309.
@@ -251,6 +288,27 @@ class Spectral:
         layout = Layout(fmt, {info.id[c]: Component((info.factor_x[c], info.factor_y[c]), c) for c in range(n)})
         return cls.from_host(ctx, (info.width, info.height), layout, planes, [quanta[c] for c in range(n)],
                              q=list(range(n)))
+
+
+def _scan_array(scans):
+    """[(component index, dc selector, ac selector), ...] per scan -> jpeg_amd_scan[]
+    (the JPEG.Header.Scan.sequential(...) constructor, jpeg.swift:1655-1700)."""
+    arr = (_lib.Scan * len(scans))()
+    for i, sc in enumerate(scans):
+        sc = sorted(sc)
+        arr[i].ncomponents = len(sc)
+        for j, (c, dc, ac) in enumerate(sc):
+            arr[i].component[j], arr[i].dc[j], arr[i].ac[j] = c, dc, ac
+    return arr
+
+
+def _jfif(jfif):
+    """jfif: None or (version_minor, unit, density_x, density_y) -- JPEG.JFIF(version:density:)."""
+    if jfif is None:
+        return None
+    j = _lib.Jfif()
+    j.version_minor, j.unit, j.density_x, j.density_y = jfif
+    return j
 
 
 def _file_bytes(source) -> np.ndarray:
@@ -428,6 +486,12 @@ class Rectangular:
             ctx.handle, C.byref(L), pixels.data_ptr(), color.code, qptr, len(tables), _ptrs(out)),
             "jpeg_amd_encode", ctx.handle)
         return Spectral(ctx, size, layout, out, tables, q)
+
+    def compress(self, quanta: Dict[int, Sequence[int]], scans, process: str = "baseline", jfif=None,
+                 path=None) -> bytes:
+        """Rectangular.compress(stream:quanta:) / compress(path:quanta:) -- encode.swift:2031,
+        os.swift:412: decomposed().fdct(quanta:).compress(...)."""
+        return self.decomposed().fdct(quanta).compress(scans, process=process, jfif=jfif, path=path)
 
     def host_values(self) -> np.ndarray:
         return self.values.cpu().numpy().view(np.uint16)

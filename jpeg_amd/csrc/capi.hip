@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "kernels.hpp"
@@ -752,6 +753,45 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
         L.qi[c] = c;
     }
     return jpeg_amd_host_decode(ctx, &L, coef, &quanta[0][0], fi.ncomponents, cosited, color, h_pixels);
+}
+
+// ---- pixels -> JPEG bytes (the fused device path + host entropy encode) ----------------------
+int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels,
+                      jpeg_amd_color color, const int32_t *quanta_key, const uint16_t *h_quanta,
+                      const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans,
+                      int nscans, const jpeg_amd_jfif *jfif, uint8_t *h_out, size_t capacity,
+                      size_t *nbytes)
+{
+    JA_TRY(bind(ctx));
+    if (!frame || !h_pixels || !quanta_key || !h_quanta || !h_quanta_keys || !scans || !nbytes) return JPEG_AMD_EINVAL;
+    const int nc = frame->ncomponents;
+    // JPEG.Common: 8-bit, arity 1 or 3 (jpeg.swift:357-424)
+    if (frame->precision != 8 || (nc != 1 && nc != 3)) return JPEG_AMD_ENOSUP;
+    if (frame->width < 1 || frame->height < 1 || ntables < 1 || ntables > JPEG_AMD_MAX_PLANES) return JPEG_AMD_EINVAL;
+
+    jpeg_amd_layout L{};
+    L.width = frame->width; L.height = frame->height; L.precision = 8; L.nplanes = nc;
+    L.scale_x = L.scale_y = 1;
+    for (int c = 0; c < nc; ++c) {
+        if (frame->factor_x[c] < 1 || frame->factor_y[c] < 1) return JPEG_AMD_EINVAL;
+        L.factor_x[c] = frame->factor_x[c]; L.factor_y[c] = frame->factor_y[c];
+        L.scale_x = std::max(L.scale_x, L.factor_x[c]); L.scale_y = std::max(L.scale_y, L.factor_y[c]);
+        L.qi[c] = -1;
+        for (int t = 0; t < ntables; ++t) if (h_quanta_keys[t] == quanta_key[c]) L.qi[c] = t;
+        if (L.qi[c] < 0) return JPEG_AMD_EINVAL;   // missing quantization table (decode.swift:2527)
+    }
+    JA_TRY(jpeg_amd_layout_units(&L));
+    frame->scale_x = L.scale_x; frame->scale_y = L.scale_y;
+    std::vector<std::vector<int16_t>> planes((size_t)nc);
+    int16_t *coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int c = 0; c < nc; ++c) {
+        frame->units_x[c] = L.units_x[c]; frame->units_y[c] = L.units_y[c];
+        planes[c].resize((size_t)64 * L.units_x[c] * L.units_y[c]);
+        coef[c] = planes[c].data();
+    }
+    JA_TRY(jpeg_amd_host_encode(ctx, &L, h_pixels, color, h_quanta, ntables, coef));
+    return jpeg_amd_jpeg_encode_spectral(frame, quanta_key, coef, h_quanta, h_quanta_keys, ntables, scans, nscans,
+                                         jfif, h_out, capacity, nbytes);
 }
 
 }  // extern "C"

@@ -1,0 +1,447 @@
+// entropy_encode.cpp -- host-side Huffman entropy ENCODER and JPEG file writer.
+//
+// SURVEY.md section 8f-3 ("next" row): the stage the GPU encode path feeds.  Input is what
+// k_encode_fused / Planar.fdct(quanta:) produce -- one int16 zigzag plane per component plus
+// the quantisation tables -- output is the byte stream Spectral.compress(stream:) writes
+// (encode.swift:1918-1972).  The target is byte-for-byte equality with the reference's own
+// files (examples/encode-basic/*.jpg, pinned by SHA-256 in tests/golden/MANIFEST.json), so the
+// places where the reference differs from a textbook encoder are mirrored and cited:
+//   - optimal Huffman lengths from a binary min-heap with strict `<` sift tests, a zero-weight
+//     dummy leaf for the all-ones code, 16-bit length limiting by promoting node pairs and
+//     splitting leaves from level 15 upwards                      encode.swift:597-760, common.swift:127-300
+//   - symbols ordered by decreasing frequency, ties in ascending symbol value (stable sort)  :716-731
+//   - a run of 16 zeros is emitted as ZRL as soon as it is complete, also when only zeros
+//     follow (so trailing zeros cost ZRLs before the EOB, and a trailing run that is a
+//     multiple of 16 ends WITHOUT an EOB)                         :917-958
+//   - non-interleaved scans walk the plane's own units, interleaved scans walk MCUs and read
+//     zero blocks outside the plane                               :962-1011, 1211-1384, decode.swift:1455-1468
+//   - one DQT segment per group of tables that come alive at the same scan, one DHT segment
+//     (DC tables, then AC tables) in front of every scan, quantisation-table slots assigned by
+//     lifetime                                                     :1936-1969, jpeg.swift:1383-1442
+// Where the reference iterates a Swift Dictionary (hash order, not reproducible) this file
+// uses ascending key order; the reference's committed files agree with that choice.
+// Sequential (baseline / extended Huffman) scans only; progressive encoding returns ENOSUP.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/jpeg_amd.h"
+
+namespace {
+
+// ---- Huffman code construction ----------------------------------------------------------
+struct Codebook {
+    uint16_t code[256];
+    uint8_t  length[256];
+    uint8_t  counts[16];            // codes per length 1..16
+    std::vector<uint8_t> symbols;   // in code order
+};
+
+// binary min-heap on (weight, tree node), 1-based like the textbook; every comparison is a
+// strict `<`, the right child wins only when strictly smaller than the left
+struct MinHeap {
+    struct Item { long key; int node; };
+    std::vector<Item> a;   // a[0] unused
+    MinHeap() : a(1) {}
+    int count() const { return (int)a.size() - 1; }
+    void sift_up(int i)
+    {
+        for (int p = i >> 1; p >= 1 && a[i].key < a[p].key; i = p, p = i >> 1) std::swap(a[i], a[p]);
+    }
+    void sift_down(int i)
+    {
+        const int n = count();
+        for (;;) {
+            const int l = 2 * i, r = l + 1;
+            if (l > n) return;
+            int c = l;
+            if (r <= n && a[r].key < a[l].key) c = r;
+            if (!(a[c].key < a[i].key)) return;
+            std::swap(a[i], a[c]);
+            i = c;
+        }
+    }
+    void heapify() { for (int i = count() >> 1; i >= 1; --i) sift_down(i); }
+    void push(long key, int node) { a.push_back({key, node}); sift_up(count()); }
+    bool pop(Item &out)
+    {
+        const int n = count();
+        if (n == 0) return false;
+        if (n > 1) std::swap(a[1], a[n]);
+        out = a.back();
+        a.pop_back();
+        if (n > 1) sift_down(1);
+        return true;
+    }
+};
+
+// leaves per depth 1.. of the merge tree -> at most 16 levels, all-ones code removed
+std::vector<int> limit_levels(std::vector<int> levels, int height)
+{
+    if ((int)levels.size() <= height) {
+        levels.back() -= 1;
+        return levels;
+    }
+    int unhoused = 0;
+    for (int l = (int)levels.size() - 1; l >= height; --l) {
+        const int pairs = levels[l] >> 1;   // a full tree: even count on every level below the root
+        unhoused += pairs;
+        levels[l - 1] += pairs;
+    }
+    levels.resize(height);
+    int split = height - 2;
+    while (unhoused > 0) {
+        if (levels[split] <= 0) { --split; continue; }
+        const int resettled = std::min(levels[split], unhoused);
+        unhoused -= resettled;
+        levels[split] -= resettled;
+        levels[split + 1] += 2 * resettled;
+        if (split < height - 2) ++split;
+    }
+    levels[height - 1] -= 1;
+    return levels;
+}
+
+bool build_codebook(const long freq[256], Codebook &cb)
+{
+    struct Entry { long f; int sym; };
+    std::vector<Entry> sorted;
+    for (int v = 0; v < 256; ++v)
+        if (freq[v] > 0) sorted.push_back({freq[v], v});
+    if (sorted.empty()) return false;
+    std::stable_sort(sorted.begin(), sorted.end(), [](const Entry &x, const Entry &y) { return x.f > y.f; });
+
+    struct Node { int left, right; };   // leaf: left < 0
+    std::vector<Node> nodes;
+    MinHeap heap;
+    for (auto it = sorted.rbegin(); it != sorted.rend(); ++it) {
+        nodes.push_back({-1, -1});
+        heap.a.push_back({it->f, (int)nodes.size() - 1});
+    }
+    heap.heapify();
+    nodes.push_back({-1, -1});
+    heap.push(0, (int)nodes.size() - 1);   // the dummy that will own the all-ones code
+
+    MinHeap::Item first, second;
+    int root = -1;
+    while (heap.pop(first)) {
+        if (!heap.pop(second)) { root = first.node; break; }
+        nodes.push_back({first.node, second.node});
+        heap.push(first.key + second.key, (int)nodes.size() - 1);
+    }
+    // leaves per depth, breadth first; the root level is dropped
+    std::vector<int> levels;
+    std::vector<int> queue{root}, next;
+    bool is_root = true;
+    while (!queue.empty()) {
+        int leaves = 0;
+        next.clear();
+        for (int n : queue) {
+            if (nodes[n].left < 0) ++leaves;
+            else { next.push_back(nodes[n].left); next.push_back(nodes[n].right); }
+        }
+        if (!is_root) levels.push_back(leaves);
+        is_root = false;
+        queue.swap(next);
+    }
+    if (levels.empty()) return false;
+    const std::vector<int> limited = limit_levels(levels, 16);
+
+    std::memset(&cb.code, 0, sizeof cb.code);
+    std::memset(&cb.length, 0, sizeof cb.length);
+    std::memset(&cb.counts, 0, sizeof cb.counts);
+    cb.symbols.clear();
+    unsigned counter = 0;
+    size_t base = 0;
+    for (int l = 0; l < 16; ++l) {
+        const int leaves = l < (int)limited.size() ? limited[l] : 0;
+        if (leaves < 0 || base + (size_t)leaves > sorted.size() || leaves > 255) return false;
+        cb.counts[l] = (uint8_t)leaves;
+        for (int i = 0; i < leaves; ++i, ++counter) {
+            const int sym = sorted[base + i].sym;
+            cb.code[sym] = (uint16_t)counter;
+            cb.length[sym] = (uint8_t)(l + 1);
+            cb.symbols.push_back((uint8_t)sym);
+        }
+        base += (size_t)leaves;
+        counter <<= 1;
+    }
+    return base == sorted.size();
+}
+
+// ---- symbols of one block (T.81 F.1.2 with the reference's eager ZRL) --------------------
+inline void compact(int16_t x, int &binade, unsigned &tail)
+{
+    const int v = x;
+    const unsigned mag = (unsigned)(v < 0 ? -v : v);
+    binade = mag ? 32 - __builtin_clz(mag) : 0;
+    const unsigned sign = (unsigned)(uint16_t)x >> 15;
+    tail = ((unsigned)(uint16_t)x - sign) & ((1u << binade) - 1u);
+}
+
+struct Sink {   // either counts symbols or writes bits
+    long *dc_freq = nullptr, *ac_freq = nullptr;
+    const Codebook *dc = nullptr, *ac = nullptr;
+    std::vector<uint8_t> *out = nullptr;
+    uint64_t acc = 0;
+    int nacc = 0;
+
+    void bits(unsigned v, int n)
+    {
+        if (n == 0) return;
+        acc = (acc << n) | (v & ((1u << n) - 1u));
+        nacc += n;
+        while (nacc >= 8) {
+            const uint8_t b = (uint8_t)(acc >> (nacc - 8));
+            out->push_back(b);
+            if (b == 0xff) out->push_back(0x00);
+            nacc -= 8;
+        }
+    }
+    void finish()
+    {
+        if (nacc > 0) bits((1u << (8 - nacc)) - 1u, 8 - nacc);   // pad with 1-bits
+    }
+    void dc_symbol(int sym, unsigned tail, int n)
+    {
+        if (out) { bits(dc->code[sym], dc->length[sym]); bits(tail, n); }
+        else ++dc_freq[sym];
+    }
+    void ac_symbol(int sym, unsigned tail, int n)
+    {
+        if (out) { bits(ac->code[sym], ac->length[sym]); bits(tail, n); }
+        else ++ac_freq[sym];
+    }
+};
+
+const int16_t kZeroBlock[64] = {0};
+
+void encode_block(const int16_t *blk, int16_t &pred, Sink &s)
+{
+    int binade;
+    unsigned tail;
+    compact((int16_t)(blk[0] - pred), binade, tail);   // wrapping 16-bit difference
+    pred = blk[0];
+    s.dc_symbol(binade, tail, binade);
+    int zeroes = 0;
+    for (int z = 1; z < 64; ++z) {
+        const int16_t c = blk[z];
+        if (c == 0) {
+            if (zeroes == 15) { s.ac_symbol(0xf0, 0, 0); zeroes = 0; }
+            else ++zeroes;
+        } else {
+            compact(c, binade, tail);
+            s.ac_symbol(zeroes << 4 | binade, tail, binade);
+            zeroes = 0;
+        }
+    }
+    if (zeroes > 0) s.ac_symbol(0x00, 0, 0);   // EOB (run of 1 block)
+}
+
+struct Plane {
+    const int16_t *coef;
+    int ux, uy, fx, fy;
+    const int16_t *at(int x, int y) const
+    {
+        return (x < ux && y < uy) ? coef + (size_t)64 * ((size_t)ux * y + x) : kZeroBlock;
+    }
+};
+
+void put16(std::vector<uint8_t> &o, unsigned v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
+void segment(std::vector<uint8_t> &o, uint8_t marker, const std::vector<uint8_t> &body)
+{
+    o.push_back(0xff); o.push_back(marker);
+    put16(o, (unsigned)body.size() + 2);
+    o.insert(o.end(), body.begin(), body.end());
+}
+
+}  // namespace
+
+extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_t *quanta_key,
+                                             const int16_t *const h_coef[], const uint16_t *h_quanta,
+                                             const int32_t *h_quanta_keys, int ntables,
+                                             const jpeg_amd_scan *scans, int nscans,
+                                             const jpeg_amd_jfif *jfif, uint8_t *h_out, size_t capacity,
+                                             size_t *nbytes)
+{
+    if (!frame || !quanta_key || !h_coef || !h_quanta || !h_quanta_keys || !scans || !nbytes) return JPEG_AMD_EINVAL;
+    const int nc = frame->ncomponents;
+    if (nc < 1 || nc > JPEG_AMD_MAX_PLANES || nscans < 1 || ntables < 1) return JPEG_AMD_EINVAL;
+    if (frame->width < 1 || frame->height < 1 || frame->width > 65535 || frame->height > 65535) return JPEG_AMD_EINVAL;
+    if (frame->process == 2) return JPEG_AMD_ENOSUP;             // progressive: not written yet
+    if (frame->process != 0 && frame->process != 1) return JPEG_AMD_EINVAL;
+    if (frame->precision != 8 && !(frame->process == 1 && frame->precision == 12)) return JPEG_AMD_EINVAL;
+
+    std::vector<Plane> planes((size_t)nc);
+    for (int c = 0; c < nc; ++c) {
+        if (!h_coef[c] || frame->units_x[c] < 1 || frame->units_y[c] < 1) return JPEG_AMD_EINVAL;
+        if (frame->factor_x[c] < 1 || frame->factor_x[c] > 4 || frame->factor_y[c] < 1 || frame->factor_y[c] > 4) return JPEG_AMD_EINVAL;
+        if (c && frame->id[c] <= frame->id[c - 1]) return JPEG_AMD_EINVAL;   // ascending ids = frame header order
+        planes[c] = {h_coef[c], frame->units_x[c], frame->units_y[c], frame->factor_x[c], frame->factor_y[c]};
+    }
+    auto table_of = [&](int key) -> const uint16_t * {
+        for (int t = 0; t < ntables; ++t) if (h_quanta_keys[t] == key) return h_quanta + 64 * t;
+        return nullptr;
+    };
+    for (int c = 0; c < nc; ++c) if (!table_of(quanta_key[c])) return JPEG_AMD_EINVAL;   // "missing quantization table"
+    for (int i = 0; i < nscans; ++i) {
+        const jpeg_amd_scan &sc = scans[i];
+        if (sc.ncomponents < 1 || sc.ncomponents > nc) return JPEG_AMD_EINVAL;
+        int volume = 0;
+        for (int j = 0; j < sc.ncomponents; ++j) {
+            const int c = sc.component[j];
+            if (c < 0 || c >= nc || (j && c <= sc.component[j - 1])) return JPEG_AMD_EINVAL;
+            const int lim = frame->process == 0 ? 1 : 3;
+            if (sc.dc[j] < 0 || sc.dc[j] > lim || sc.ac[j] < 0 || sc.ac[j] > lim) return JPEG_AMD_EINVAL;
+            volume += planes[c].fx * planes[c].fy;
+        }
+        if (sc.ncomponents > 1 && volume > 10) return JPEG_AMD_EINVAL;
+    }
+
+    // ---- quantisation-table slots by lifetime, table definition groups ----
+    std::vector<int> keys;                       // distinct keys, ascending
+    for (int c = 0; c < nc; ++c) keys.push_back(quanta_key[c]);
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    struct Life { int start = -1, end = -1, slot = 0; };
+    std::vector<Life> life(keys.size());
+    auto key_index = [&](int key) { return (int)(std::find(keys.begin(), keys.end(), key) - keys.begin()); };
+    for (int i = 0; i < nscans; ++i)
+        for (int j = 0; j < scans[i].ncomponents; ++j) {
+            Life &l = life[(size_t)key_index(quanta_key[scans[i].component[j]])];
+            if (l.start < 0) l.start = i;
+            l.end = i + 1;
+        }
+    int slot_time[4] = {0, 0, 0, 0};
+    const int nslots = frame->process == 0 ? 2 : 4;
+    for (Life &l : life) {
+        if (l.start < 0) continue;               // no scan references it: selector 0
+        int s = 0;
+        while (s < nslots && l.start < slot_time[s]) ++s;
+        if (s == nslots) return JPEG_AMD_EINVAL; // "not enough free quantization table slots"
+        slot_time[s] = l.end;
+        l.slot = s;
+    }
+    std::vector<int> starts;
+    for (const Life &l : life) if (l.start >= 0) starts.push_back(l.start);
+    std::sort(starts.begin(), starts.end());
+    starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+    if (starts.empty() || starts[0] != 0) return JPEG_AMD_EINVAL;
+
+    // ---- file ----
+    std::vector<uint8_t> out;
+    out.reserve(capacity ? capacity : 1 << 16);
+    out.push_back(0xff); out.push_back(0xd8);
+    if (jfif) {
+        if (jfif->version_minor < 0 || jfif->version_minor > 2 || jfif->unit < 0 || jfif->unit > 2) return JPEG_AMD_EINVAL;
+        std::vector<uint8_t> b{'J', 'F', 'I', 'F', 0, 1, (uint8_t)jfif->version_minor, (uint8_t)jfif->unit};
+        put16(b, (unsigned)jfif->density_x); put16(b, (unsigned)jfif->density_y);
+        b.push_back(0); b.push_back(0);
+        segment(out, 0xe0, b);
+    }
+    {
+        std::vector<uint8_t> b{(uint8_t)frame->precision};
+        put16(b, (unsigned)frame->height); put16(b, (unsigned)frame->width);
+        b.push_back((uint8_t)nc);
+        for (int c = 0; c < nc; ++c) {
+            b.push_back((uint8_t)frame->id[c]);
+            b.push_back((uint8_t)(planes[c].fx << 4 | planes[c].fy));
+            b.push_back((uint8_t)life[(size_t)key_index(quanta_key[c])].slot);
+        }
+        segment(out, frame->process == 0 ? 0xc0 : 0xc1, b);
+    }
+    int scale_x = 1, scale_y = 1;                // Layout.scale: max factor over the components
+    for (const Plane &p : planes) { scale_x = std::max(scale_x, p.fx); scale_y = std::max(scale_y, p.fy); }
+    const int mcux = (frame->width + 8 * scale_x - 1) / (8 * scale_x);
+    const int mcuy = (frame->height + 8 * scale_y - 1) / (8 * scale_y);
+    for (size_t g = 0; g < starts.size(); ++g) {
+        {   // DQT: every table whose lifetime starts with this group
+            std::vector<uint8_t> b;
+            for (size_t k = 0; k < keys.size(); ++k) {
+                if (life[k].start != starts[g]) continue;
+                const uint16_t *q = table_of(keys[k]);
+                if (frame->precision > 8) {
+                    b.push_back((uint8_t)(0x10 | life[k].slot));
+                    for (int z = 0; z < 64; ++z) put16(b, q[z]);
+                } else {
+                    b.push_back((uint8_t)life[k].slot);
+                    for (int z = 0; z < 64; ++z) {
+                        if (q[z] > 255) return JPEG_AMD_EINVAL;   // "8-bit quantization table values must be representable"
+                        b.push_back((uint8_t)q[z]);
+                    }
+                }
+            }
+            if (!b.empty()) segment(out, 0xdb, b);
+        }
+        const int end = g + 1 < starts.size() ? starts[g + 1] : nscans;
+        for (int i = starts[g]; i < end; ++i) {
+            const jpeg_amd_scan &sc = scans[i];
+            const int ns = sc.ncomponents;
+            // pass 1: symbol statistics per table selector
+            long dc_freq[4][256], ac_freq[4][256];
+            std::memset(dc_freq, 0, sizeof dc_freq);
+            std::memset(ac_freq, 0, sizeof ac_freq);
+            auto walk = [&](bool emit, std::vector<uint8_t> *ecs, const Codebook *dcb, const Codebook *acb) {
+                Sink s;
+                s.out = emit ? ecs : nullptr;
+                int16_t pred[4] = {0, 0, 0, 0};
+                auto select = [&](int j) {
+                    s.dc_freq = dc_freq[sc.dc[j]]; s.ac_freq = ac_freq[sc.ac[j]];
+                    if (emit) { s.dc = dcb + sc.dc[j]; s.ac = acb + sc.ac[j]; }
+                };
+                if (ns == 1) {
+                    const Plane &p = planes[sc.component[0]];
+                    select(0);
+                    for (int y = 0; y < p.uy; ++y)
+                        for (int x = 0; x < p.ux; ++x) encode_block(p.at(x, y), pred[0], s);
+                } else {
+                    for (int my = 0; my < mcuy; ++my)
+                        for (int mx = 0; mx < mcux; ++mx)
+                            for (int j = 0; j < ns; ++j) {
+                                const Plane &p = planes[sc.component[j]];
+                                select(j);
+                                for (int by = 0; by < p.fy; ++by)
+                                    for (int bx = 0; bx < p.fx; ++bx)
+                                        encode_block(p.at(mx * p.fx + bx, my * p.fy + by), pred[j], s);
+                            }
+                }
+                if (emit) s.finish();
+            };
+            walk(false, nullptr, nullptr, nullptr);
+            Codebook dcb[4], acb[4];
+            bool dc_used[4] = {false, false, false, false}, ac_used[4] = {false, false, false, false};
+            for (int j = 0; j < ns; ++j) { dc_used[sc.dc[j]] = true; ac_used[sc.ac[j]] = true; }
+            std::vector<uint8_t> dht;
+            for (int t = 0; t < 4; ++t)
+                if (dc_used[t]) {
+                    if (!build_codebook(dc_freq[t], dcb[t])) return JPEG_AMD_EINVAL;
+                    dht.push_back((uint8_t)t);
+                    dht.insert(dht.end(), dcb[t].counts, dcb[t].counts + 16);
+                    dht.insert(dht.end(), dcb[t].symbols.begin(), dcb[t].symbols.end());
+                }
+            for (int t = 0; t < 4; ++t)
+                if (ac_used[t]) {
+                    if (!build_codebook(ac_freq[t], acb[t])) return JPEG_AMD_EINVAL;
+                    dht.push_back((uint8_t)(0x10 | t));
+                    dht.insert(dht.end(), acb[t].counts, acb[t].counts + 16);
+                    dht.insert(dht.end(), acb[t].symbols.begin(), acb[t].symbols.end());
+                }
+            segment(out, 0xc4, dht);
+            std::vector<uint8_t> sos{(uint8_t)ns};
+            for (int j = 0; j < ns; ++j) {
+                sos.push_back((uint8_t)frame->id[sc.component[j]]);
+                sos.push_back((uint8_t)(sc.dc[j] << 4 | sc.ac[j]));
+            }
+            sos.push_back(0); sos.push_back(63); sos.push_back(0);
+            segment(out, 0xda, sos);
+            walk(true, &out, dcb, acb);
+        }
+    }
+    out.push_back(0xff); out.push_back(0xd9);
+
+    *nbytes = out.size();
+    if (!h_out || capacity < out.size()) return h_out ? JPEG_AMD_EINVAL : JPEG_AMD_OK;   // size query with h_out == NULL
+    std::memcpy(h_out, out.data(), out.size());
+    return JPEG_AMD_OK;
+}

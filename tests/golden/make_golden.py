@@ -135,7 +135,10 @@ def main():
                  "factors": [list(lf), [1, 1], [1, 1]],
                  "units": [[c.ux, c.uy] for c in img.components],
                  "quanta_zigzag": [q.tolist() for q in img.quanta],
-                 "coef_sha256": [sha(np.ascontiguousarray(p).tobytes()) for p in img.planes]}
+                 "coef_sha256": [sha(np.ascontiguousarray(p).tobytes()) for p in img.planes],
+                 # the reference's own output file: pins the entropy encoder + file writer byte for byte
+                 "file_sha256": sha_file(os.path.join(enc, fn)),
+                 "file_nbytes": os.path.getsize(os.path.join(enc, fn))}
             if level in keep:
                 copy(os.path.join(enc, fn), os.path.join(HERE, "encode", fn))
                 c["file"] = "encode/" + fn

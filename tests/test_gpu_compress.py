@@ -1,0 +1,72 @@
+"""jpeg_amd_compress: pixels -> JPEG file bytes (GPU spectral path + host entropy encoder,
+SURVEY.md 8f-3).  The pins are the reference's own 32 output files of examples/encode-basic
+(4 subsampling modes x 8 quality levels), by SHA-256 and, for the 8 committed ones, byte by byte."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import _golden as G
+from jpeg_amd import _lib
+from jpeg_amd.api import _scan_array, _jfif
+
+pytestmark = pytest.mark.gpu
+
+SCANS = [[(0, 0, 0)], [(1, 1, 1), (2, 1, 1)]]      # examples/encode-basic/main.swift:42-46
+JFIF = (2, 2, 1, 1)                                # .init(version: .v1_2, density: (1, 1, .centimeters))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import jpeg_amd as J
+    return J.Context()
+
+
+def _quanta(level):
+    import jpeg_amd as J
+    return np.stack([J.compression_quanta("luminance", level), J.compression_quanta("chrominance", level)]).astype(np.uint16)
+
+
+@pytest.mark.parametrize("case", G.encode_cases(), ids=lambda c: f"{c['mode']}-{c['level']}")
+def test_compress_reproduces_the_references_file(ctx, case):
+    import jpeg_amd as J
+    rgb, (w, h) = G.encode_source()
+    info = _lib.FrameInfo()
+    info.width, info.height, info.precision, info.ncomponents, info.process = w, h, 8, 3, 0
+    for c, (fx, fy) in enumerate(case["factors"]):
+        info.id[c], info.factor_x[c], info.factor_y[c] = c + 1, fx, fy
+    tables = _quanta(case["level"])
+    assert [t.tolist() for t in tables] == case["quanta_zigzag"][:2]
+    qkey = (C.c_int32 * 3)(0, 1, 1)
+    tk = (C.c_int32 * 2)(0, 1)
+    sarr, j, n = _scan_array(SCANS), _jfif(JFIF), C.c_size_t()
+    out = np.empty(1 << 20, np.uint8)
+    px = np.ascontiguousarray(rgb)
+    st = _lib.lib().jpeg_amd_compress(ctx.handle, C.byref(info), px.ctypes.data, J.RGB.code, qkey, tables.ctypes.data,
+                                      tk, 2, sarr, 2, C.byref(j), out.ctypes.data, out.size, C.byref(n))
+    assert st == 0, st
+    assert [[info.units_x[c], info.units_y[c]] for c in range(3)] == case["units"]
+    got = out[:n.value]
+    assert n.value == case["file_nbytes"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == case["file_sha256"]
+    if "file" in case:
+        assert (got == np.fromfile(G.path(case["file"]), np.uint8)).all()
+
+
+@pytest.mark.parametrize("mode", ["4-2-0", "4-4-4"])
+def test_python_mirror_compress_then_decompress(ctx, mode, tmp_path):
+    """Rectangular.pack(...).compress(path:quanta:) then Rectangular.decompress(path:) -- the
+    reference's own round trip (examples/encode-basic + decode-basic)."""
+    import jpeg_amd as J
+    case = next(c for c in G.encode_cases() if c["mode"] == mode and c["level"] == 1.0)
+    rgb, size = G.encode_source()
+    layout = J.Layout("ycc8", {1: (tuple(case["factors"][0]), 0), 2: ((1, 1), 1), 3: ((1, 1), 1)})
+    quanta = {0: J.compression_quanta("luminance", 1.0), 1: J.compression_quanta("chrominance", 1.0)}
+    path = str(tmp_path / "out.jpg")
+    data = J.Rectangular.pack(ctx, size, layout, rgb, J.RGB).compress(quanta, SCANS, jfif=JFIF, path=path)
+    assert hashlib.sha256(data).hexdigest() == case["file_sha256"]
+    back = J.Rectangular.decompress(ctx, path).unpack(J.RGB).cpu().numpy()
+    err = back.astype(np.int32) - rgb.astype(np.int32)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean(err.astype(np.float64) ** 2))
+    assert psnr > 25.0, psnr

@@ -68,8 +68,8 @@ __device__ __forceinline__ void rgb_to_ycc(float r, float g, float b, float &y, 
 // on the GPU that n equals the reference's integer for EVERY float numerator below 2^17 and
 // EVERY divisor an 8-bit quantisation table can produce (7140 divisors x 1.2e9 numerators,
 // profiles/r01_verify_div.txt); the fused kernel only runs for 8-bit formats.
-__device__ __forceinline__ void fdct_quantise_store(const float (&g)[64], const float *q, const float *rq,
-                                                    int16_t *dst)
+__device__ __forceinline__ void fdct_quantise(const float (&g)[64], const float *q, const float *rq,
+                                              uint32_t (&w)[32])
 {
     float f[64];  // f[8k + y]: horizontal pass (encode.swift:193), level shift 2^(P-1) * 8
 #pragma unroll
@@ -85,7 +85,7 @@ __device__ __forceinline__ void fdct_quantise_store(const float (&g)[64], const 
     // arithmetic of all eight columns around the table reads and needs > 200 VGPRs (spills).
 #pragma unroll
     for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(f[i]));
-    uint32_t w[32];   // 64 quantised coefficients, zigzag order, packed in pairs
+    // w: 64 quantised coefficients, zigzag order, packed in pairs
 #pragma unroll
     for (int m = 0; m < 32; ++m) w[m] = 0;
 #pragma unroll
@@ -108,9 +108,38 @@ __device__ __forceinline__ void fdct_quantise_store(const float (&g)[64], const 
             asm volatile("" : "+v"(w[z >> 1]));
         }
     }
-    uint4 *o = reinterpret_cast<uint4 *>(dst);
+}
+
+// Store the 64 blocks a wave has just quantised (one per lane, w = 128 bytes each).  A lane
+// storing its own block would write 16 bytes of eight different 128-byte lines per instruction
+// and revisit every line eight times; partial-line writes are what this kernel used to spend a
+// third of its time on.  Instead the blocks go through a wave-private 8 KiB LDS buffer (chunk c
+// of lane L at slot c ^ ((L >> 1) & 7), conflict-free for the stride-128-byte writes) and come
+// back lane-linear: instruction i writes the complete lines of blocks 8i .. 8i + 7, each lane one
+// 16-byte chunk, with the `nt` hint (streaming output).  `offset` = byte offset of the lane's
+// block from `plane` (wave-uniform), or ~0u for a block outside the plane; the producer's offset
+// reaches the storing lane through ds_bpermute.  LDS operations of one wave execute in order, so
+// no barrier is needed; all 64 lanes must call this together.
+__device__ __forceinline__ void wave_store_blocks(const uint32_t (&w)[32], uint32_t *stage, int lane,
+                                                  int16_t *plane, uint32_t offset)
+{
+    uint4 *mine = reinterpret_cast<uint4 *>(stage) + 8 * lane;
+    const int sw = (lane >> 1) & 7;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    for (int c = 0; c < 8; ++c) mine[c ^ sw] = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+    const uint4 *all = reinterpret_cast<const uint4 *>(stage);
+    char *base = reinterpret_cast<char *>(plane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int producer = 8 * i + (lane >> 3);
+        const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * producer, (int)offset);
+        const int c = (lane & 7) ^ ((producer >> 1) & 7);
+        const uint4 v = all[64 * i + lane];
+#ifdef JA_X_ENC_NOSTORE
+        if (plane == nullptr)
+#endif
+        if (off != ~0u) store_nt16(base + off + 16 * c, v);
+    }
 }
 
 // SX, SY: chroma subsampling (1 or 2) per axis; RGB: input is RGB8 (else YCbCr8);
@@ -119,16 +148,26 @@ __device__ __forceinline__ void fdct_quantise_store(const float (&g)[64], const 
 template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN>
 __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
 {
-    constexpr int CW = ETX * 8 / SX, CH = ETY * 8 / SY;  // chroma samples per tile
-    constexpr int CPITCH = CW / 4;                       // dwords per LDS row
     constexpr bool INTHREAD = SX == 1 && SY == 1;        // 4:4:4: chroma block == the luma block's pixels
+    // 4:2:2 / 4:4:0: the 8 luma block rows of one `half` already hold 256 chroma blocks (one per
+    // work-item), so the chroma tile covers one half at a time and stays at 16 KiB
+    constexpr bool PERHALF = CHROMA && SX * SY == 2;
+    constexpr int CW = ETX * 8 / SX, CH = (PERHALF ? ETY / 2 : ETY) * 8 / SY;  // chroma samples per tile (or half)
+    constexpr int CPITCH = CW / 4;                       // dwords per LDS row
     __shared__ uint32_t sc[(CHROMA && !INTHREAD) ? 2 * CH * CPITCH : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[kThreads / 64][64 * 32];  // 8 KiB per wave
+    // 4:4:4: the block's Cb / Cr samples wait here (packed 4 per dword, [dword][lane]) while the
+    // luma block is transformed -- in registers they cost 32 VGPRs and the kernel spilled
+    __shared__ uint32_t stash_all[(CHROMA && INTHREAD) ? kThreads / 64 : 1][(CHROMA && INTHREAD) ? 32 * 64 : 1];
     __shared__ float sq[3][64];   // modulated tables (scale 8) ...
     __shared__ float sr[3][64];   // ... and their correctly rounded reciprocals
 
     const int img = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
     const int lbx = threadIdx.x & (ETX - 1), lby0 = threadIdx.x / ETX;
+    const int lane = threadIdx.x & 63;
+    uint32_t *stage = stage_all[threadIdx.x >> 6];
+    uint32_t *stash = stash_all[(CHROMA && INTHREAD) ? threadIdx.x >> 6 : 0];
 
     if (threadIdx.x < 192 && (CHROMA || threadIdx.x < 64)) {
         const int t = threadIdx.x >> 6, k = threadIdx.x & 7, h = (threadIdx.x >> 3) & 7;
@@ -138,13 +177,40 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
     }
     __syncthreads();
 
+    // chroma blocks of the tile (or of one half of it) from the pooled LDS tile
+    auto chroma_blocks = [&](int half) {
+        constexpr int CBX = ETX / SX, CBY = (PERHALF ? ETY / 2 : ETY) / SY;  // chroma blocks per plane
+#pragma unroll 1
+        for (int c = threadIdx.x; c < 2 * CBX * CBY; c += kThreads) {
+            const int pl = c / (CBX * CBY), r = c - pl * (CBX * CBY);
+            const int cby = r / CBX, cbx = r - cby * CBX;
+            const int bx = txi * CBX + cbx, by = tyi * (ETY / SY) + half * CBY + cby;
+            float g[64];
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                const uint32_t *row = sc + (pl * CH + 8 * cby + y) * CPITCH + 2 * cbx;
+                const uint32_t d0 = row[0], d1 = row[1];
+                g[8 * y + 0] = ubyte<0>(d0); g[8 * y + 1] = ubyte<1>(d0);
+                g[8 * y + 2] = ubyte<2>(d0); g[8 * y + 3] = ubyte<3>(d0);
+                g[8 * y + 4] = ubyte<0>(d1); g[8 * y + 5] = ubyte<1>(d1);
+                g[8 * y + 6] = ubyte<2>(d1); g[8 * y + 7] = ubyte<3>(d1);
+            }
+            uint32_t w[32];
+            fdct_quantise(g, sq[1 + pl], sr[1 + pl], w);
+            // 2 * CBX * CBY and CBX * CBY are multiples of 64: the loop is wave-uniform and a wave
+            // never straddles the two planes
+            const int plu = __builtin_amdgcn_readfirstlane(pl);
+            const uint32_t off = (bx < a.ux[1 + plu] && by < a.uy[1 + plu]) ? 128u * (uint32_t)(by * a.ux[1 + plu] + bx) : ~0u;
+            wave_store_blocks(w, stage, lane, a.coef[1 + plu] + img * a.coef_stride[1 + plu], off);
+        }
+    };
+
     const uint8_t *base = a.px + img * a.px_stride;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         const int lby = lby0 + 8 * half;
         const int bx = txi * ETX + lbx, by = tyi * ETY + lby;
         float yv[64];
-        uint32_t cpk[2][16];  // 4:4:4 only: the block's Cb / Cr samples packed 4 per dword
 
         // one pixel row of the block: Y stays in registers for the FDCT; Cb / Cr are pooled by
         // the box filter (every SY rows) into the LDS tile, or packed for the in-thread path
@@ -167,7 +233,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
                         uint32_t v = 0;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v = __builtin_amdgcn_cvt_pk_u8_f32(crow[pl][y & 1][4 * d + i], i, v);
-                        cpk[pl][2 * y + d] = v;
+                        stash[(pl * 16 + 2 * y + d) * 64 + lane] = v;
                     }
             } else if constexpr (CHROMA) {
                 if (SY == 1 || (y & 1)) {
@@ -188,7 +254,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
                             // integer sum of <= 4 bytes, exact; Float(sum) / n truncated
                             packed[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(sum * inv), i & 3, packed[i >> 2]);
                         }
-                        uint32_t *row = sc + (pl * CH + lby * (8 / SY) + j) * CPITCH + lbx * (8 / SX) / 4;
+                        uint32_t *row = sc + (pl * CH + (PERHALF ? lby0 : lby) * (8 / SY) + j) * CPITCH + lbx * (8 / SX) / 4;
 #pragma unroll
                         for (int d = 0; d < (8 / SX + 3) / 4; ++d) row[d] = packed[d];
                     }
@@ -204,7 +270,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
         if (FASTIN && inside) {
 #pragma unroll
             for (int y = 0; y < 8; ++y) {
+#ifdef JA_X_ENC_L2LOAD   // experiment: every block reads the image's first tile (L2 hits)
+                const uint2 *row = reinterpret_cast<const uint2 *>(base + ((size_t)(8 * lby + y) * a.W + 8 * lbx) * 3);
+#else
                 const uint2 *row = reinterpret_cast<const uint2 *>(base + ((size_t)(8 * by + y) * a.W + 8 * bx) * 3);
+#endif
                 const uint2 p0 = row[0], p1 = row[1], p2 = row[2];
                 pix[y][0] = p0.x; pix[y][1] = p0.y; pix[y][2] = p1.x; pix[y][3] = p1.y; pix[y][4] = p2.x; pix[y][5] = p2.y;
             }
@@ -246,48 +316,39 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
 
         // ---- luma (and 4:4:4 chroma) blocks of this position ----
         __builtin_amdgcn_sched_barrier(0);
-        if (bx < a.ux[0] && by < a.uy[0])
-            fdct_quantise_store(yv, sq[0], sr[0], a.coef[0] + img * a.coef_stride[0] + (size_t)64 * (by * a.ux[0] + bx));
+        {
+            uint32_t w[32];
+            fdct_quantise(yv, sq[0], sr[0], w);
+            const uint32_t off = (bx < a.ux[0] && by < a.uy[0]) ? 128u * (uint32_t)(by * a.ux[0] + bx) : ~0u;
+            wave_store_blocks(w, stage, lane, a.coef[0] + img * a.coef_stride[0], off);
+        }
         if constexpr (CHROMA && INTHREAD) {
 #pragma unroll 1
             for (int pl = 0; pl < 2; ++pl) {
-                if (bx >= a.ux[1 + pl] || by >= a.uy[1 + pl]) continue;
                 float g[64];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const uint32_t v = pl ? cpk[1][i] : cpk[0][i];
+                    const uint32_t v = stash[(pl * 16 + i) * 64 + lane];
                     g[4 * i + 0] = ubyte<0>(v); g[4 * i + 1] = ubyte<1>(v);
                     g[4 * i + 2] = ubyte<2>(v); g[4 * i + 3] = ubyte<3>(v);
                 }
-                fdct_quantise_store(g, sq[1 + pl], sr[1 + pl],
-                                    a.coef[1 + pl] + img * a.coef_stride[1 + pl] + (size_t)64 * (by * a.ux[1 + pl] + bx));
+                uint32_t w[32];
+                fdct_quantise(g, sq[1 + pl], sr[1 + pl], w);
+                const uint32_t off = (bx < a.ux[1 + pl] && by < a.uy[1 + pl]) ? 128u * (uint32_t)(by * a.ux[1 + pl] + bx) : ~0u;
+                wave_store_blocks(w, stage, lane, a.coef[1 + pl] + img * a.coef_stride[1 + pl], off);
             }
         }
+        if constexpr (PERHALF) {
+            __syncthreads();          // the half's chroma samples are pooled
+            chroma_blocks(half);
+            if (half == 0) __syncthreads();   // ... and consumed before the next half overwrites them
+        }
+    }
+    if constexpr (CHROMA && !INTHREAD && !PERHALF) {
+        __syncthreads();
+        chroma_blocks(0);
     }
 
-    if constexpr (CHROMA && !INTHREAD) {
-        __syncthreads();
-        constexpr int CBX = ETX / SX, CBY = ETY / SY;  // chroma blocks per tile and plane
-#pragma unroll 1
-        for (int c = threadIdx.x; c < 2 * CBX * CBY; c += kThreads) {
-            const int pl = c / (CBX * CBY), r = c - pl * (CBX * CBY);
-            const int cby = r / CBX, cbx = r - cby * CBX;
-            const int bx = txi * CBX + cbx, by = tyi * CBY + cby;
-            if (bx >= a.ux[1 + pl] || by >= a.uy[1 + pl]) continue;
-            float g[64];
-#pragma unroll
-            for (int y = 0; y < 8; ++y) {
-                const uint32_t *row = sc + (pl * CH + 8 * cby + y) * CPITCH + 2 * cbx;
-                const uint32_t d0 = row[0], d1 = row[1];
-                g[8 * y + 0] = ubyte<0>(d0); g[8 * y + 1] = ubyte<1>(d0);
-                g[8 * y + 2] = ubyte<2>(d0); g[8 * y + 3] = ubyte<3>(d0);
-                g[8 * y + 4] = ubyte<0>(d1); g[8 * y + 5] = ubyte<1>(d1);
-                g[8 * y + 6] = ubyte<2>(d1); g[8 * y + 7] = ubyte<3>(d1);
-            }
-            fdct_quantise_store(g, sq[1 + pl], sr[1 + pl],
-                                a.coef[1 + pl] + img * a.coef_stride[1 + pl] + (size_t)64 * (by * a.ux[1 + pl] + bx));
-        }
-    }
 }
 
 }  // namespace

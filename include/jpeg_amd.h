@@ -226,30 +226,48 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
  * (encode.swift:1918-1972): optimised Huffman tables per scan (:700-760), sequential scans,
  * interleaved or not (:962-1011, 1211-1384), table definitions grouped like
  * JPEG.Layout.definitions (jpeg.swift:1383-1442).  Output is byte-identical to the reference's
- * files for the same coefficients.  Progressive scan encoding is not written yet (ENOSUP). */
-typedef struct jpeg_amd_scan {                /* JPEG.Header.Scan.sequential(...) */
+ * files for the same coefficients.  Sequential and progressive (DC / AC, first pass and
+ * refinement, EOB runs: encode.swift:1013-1206, 1386-1557) Huffman scans. */
+typedef struct jpeg_amd_scan {                /* JPEG.Header.Scan (jpeg.swift:1640-1760) */
     int32_t ncomponents;
     int32_t component[JPEG_AMD_MAX_PLANES];   /* plane indices (frame order), ascending */
     int32_t dc[JPEG_AMD_MAX_PLANES];          /* Huffman table selectors 0..1 (baseline) / 0..3 */
     int32_t ac[JPEG_AMD_MAX_PLANES];
+    /* progressive process only; all zero = a sequential scan (.sequential(...)):
+     *   band_lo = 0, band_hi = 1, refine = 0: .progressive(..., bits: bit...)     DC, first pass
+     *   band_lo = 0, band_hi = 1, refine = 1: .progressive(..., bit: bit)         DC, one more bit
+     *   band_lo >= 1,             refine = 0: .progressive(c, band:, bits: bit...) AC, first pass
+     *   band_lo >= 1,             refine = 1: .progressive(c, band:, bit: bit)     AC, one more bit */
+    int32_t band_lo, band_hi;                 /* zigzag band [band_lo, band_hi) */
+    int32_t bit, refine;
 } jpeg_amd_scan;
 
-typedef struct jpeg_amd_jfif {                /* JPEG.JFIF (metadata record, APP0) */
+typedef struct jpeg_amd_jfif {                /* JPEG.JFIF */
     int32_t version_minor;                    /* 1.0, 1.1, 1.2 -> 0, 1, 2 */
     int32_t unit;                             /* 0 none, 1 dots per inch, 2 dots per centimetre */
     int32_t density_x, density_y;
 } jpeg_amd_jfif;
 
+typedef struct jpeg_amd_metadata {            /* JPEG.Metadata record, written after SOI in order */
+    int32_t kind;                             /* 0 .jfif, 1 .application(app, data:), 2 .comment(data:) */
+    int32_t app;                              /* kind 1: 0..15 */
+    jpeg_amd_jfif jfif;                       /* kind 0 */
+    const uint8_t *data;                      /* kinds 1, 2: segment payload */
+    size_t size;
+} jpeg_amd_metadata;
+
 /* frame: width, height, precision, process (0 baseline, 1 extended), ncomponents, id[] (ascending),
  * factor_*[], units_*[] of the planes in h_coef[] (int16 [units_y][units_x][64], zigzag).
  * quanta_key[c]: quantisation-table key of component c (JPEG.Table.Quantization.Key);
  * h_quanta / h_quanta_keys: ntables tables of 64 zigzag values and their keys.
- * jfif may be NULL (no APP0).  h_out == NULL only computes *nbytes. */
+ * process 2 (progressive) takes progressive scans, 0 / 1 sequential ones.
+ * h_out == NULL only computes *nbytes. */
 int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_t *quanta_key,
                                   const int16_t *const h_coef[], const uint16_t *h_quanta,
                                   const int32_t *h_quanta_keys, int ntables,
                                   const jpeg_amd_scan *scans, int nscans,
-                                  const jpeg_amd_jfif *jfif, uint8_t *h_out, size_t capacity,
+                                  const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out,
+                                  size_t capacity,
                                   size_t *nbytes);
 /* Rectangular.pack(...).compress(stream:quanta:)  (encode.swift:456, 2031; os.swift:412): H*W
  * colours of 3 bytes in host memory -> colour conversion, downsampling, FDCT and quantisation on
@@ -258,7 +276,8 @@ int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_
 int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels,
                       jpeg_amd_color color, const int32_t *quanta_key, const uint16_t *h_quanta,
                       const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans,
-                      int nscans, const jpeg_amd_jfif *jfif, uint8_t *h_out, size_t capacity,
+                      int nscans, const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out,
+                      size_t capacity,
                       size_t *nbytes);
 
 #ifdef __cplusplus

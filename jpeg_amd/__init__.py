@@ -7,9 +7,9 @@ include/jpeg_amd.h.  All arithmetic runs in hand-written HIP kernels
 """
 from ._lib import JpegAmdError, LIB_PATH  # noqa: F401
 from .api import (  # noqa: F401
-    RGB, YCbCr, Component, Context, Layout, Planar, Rectangular, Spectral,
+    RGB, YCbCr, Component, Context, Layout, Planar, Rectangular, Scan, Spectral,
     compression_quanta, default_context, inspect,
 )
 
 __all__ = ["RGB", "YCbCr", "Component", "Context", "Layout", "Planar", "Rectangular",
-           "Spectral", "JpegAmdError", "compression_quanta", "default_context", "inspect"]
+           "Scan", "Spectral", "JpegAmdError", "compression_quanta", "default_context", "inspect"]

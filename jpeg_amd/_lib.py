@@ -79,8 +79,8 @@ SIGNATURES = {
     "jpeg_amd_jpeg_inspect": (C.c_int, [_p, C.c_size_t, _p]),
     "jpeg_amd_jpeg_decode_spectral": (C.c_int, [_p, C.c_size_t, _pp, _p, _p]),
     "jpeg_amd_decompress": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_int, _p, C.c_size_t, _p]),
-    "jpeg_amd_jpeg_encode_spectral": (C.c_int, [_p, _p, _pp, _p, _p, C.c_int, _p, C.c_int, _p, _p, C.c_size_t, _p]),
-    "jpeg_amd_compress": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, _p, C.c_size_t, _p]),
+    "jpeg_amd_jpeg_encode_spectral": (C.c_int, [_p, _p, _pp, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
+    "jpeg_amd_compress": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
 }
 
 
@@ -98,12 +98,18 @@ class FrameInfo(C.Structure):
 class Scan(C.Structure):
     """struct jpeg_amd_scan"""
     _fields_ = [("ncomponents", C.c_int32), ("component", C.c_int32 * MAX_PLANES),
-                ("dc", C.c_int32 * MAX_PLANES), ("ac", C.c_int32 * MAX_PLANES)]
+                ("dc", C.c_int32 * MAX_PLANES), ("ac", C.c_int32 * MAX_PLANES),
+                ("band_lo", C.c_int32), ("band_hi", C.c_int32), ("bit", C.c_int32), ("refine", C.c_int32)]
 
 
 class Jfif(C.Structure):
     """struct jpeg_amd_jfif"""
     _fields_ = [("version_minor", C.c_int32), ("unit", C.c_int32), ("density_x", C.c_int32), ("density_y", C.c_int32)]
+
+
+class Metadata(C.Structure):
+    """struct jpeg_amd_metadata"""
+    _fields_ = [("kind", C.c_int32), ("app", C.c_int32), ("jfif", Jfif), ("data", C.c_void_p), ("size", C.c_size_t)]
 
 
 _LIB = None

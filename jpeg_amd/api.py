@@ -234,10 +234,10 @@ class Spectral:
     def host_planes(self) -> List[np.ndarray]:
         return [p.cpu().numpy() for p in self.planes]
 
-    def compress(self, scans, process: str = "baseline", jfif=None, path=None) -> bytes:
+    def compress(self, scans, process: str = "baseline", metadata=None, path=None) -> bytes:
         """Spectral.compress(stream:) / compress(path:) -- encode.swift:1918-1972, os.swift:330.
-        scans: the layout's scan progression, one list of (plane index, dc selector, ac selector)
-        per sequential scan.  The coefficient planes come back to the host and are entropy-coded
+        scans: the layout's scan progression -- Scan objects, or plain lists of (plane index, dc
+        selector, ac selector) for sequential scans; metadata: see _metadata_array.  The coefficient planes come back to the host and are entropy-coded
         there (csrc/entropy_encode.cpp).  Returns the file's bytes (and writes `path`)."""
         info = _lib.FrameInfo()
         info.width, info.height = self.size
@@ -257,10 +257,10 @@ class Spectral:
         qkey = (C.c_int32 * len(keys))(*keys)
         tk = (C.c_int32 * len(tkeys))(*tkeys)
         sarr = _scan_array(scans)
-        j = _jfif(jfif)
+        marr, nmeta, _keep = _metadata_array(metadata)
         n = C.c_size_t()
         args = [C.byref(info), qkey, _lib.ptr_array([h.ctypes.data for h in host]), tables.ctypes.data, tk, len(tkeys),
-                sarr, len(scans), C.byref(j) if j is not None else None]
+                sarr, len(scans), marr, nmeta]
         _lib.check(_lib.lib().jpeg_amd_jpeg_encode_spectral(*args, None, 0, C.byref(n)), "jpeg_amd_jpeg_encode_spectral")
         out = np.empty(n.value, np.uint8)
         _lib.check(_lib.lib().jpeg_amd_jpeg_encode_spectral(*args, out.ctypes.data, out.size, C.byref(n)),
@@ -290,25 +290,70 @@ class Spectral:
                              q=list(range(n)))
 
 
+class Scan:
+    """JPEG.Header.Scan constructors (jpeg.swift:1640-1760).  Components are PLANE INDICES
+    (frame order); table selectors are 0..3."""
+
+    def __init__(self, components, band=(0, 0), bit=0, refine=0):
+        self.components, self.band, self.bit, self.refine = sorted(components), band, bit, refine
+
+    @classmethod
+    def sequential(cls, *components):
+        """.sequential((c, dc, ac), ...)"""
+        return cls(components)
+
+    @classmethod
+    def progressive_dc(cls, *components, bits):
+        """.progressive((c, dc), ..., bits: bits...)"""
+        return cls([(c, dc, 0) for c, dc in components], (0, 1), bits, 0)
+
+    @classmethod
+    def progressive_dc_refine(cls, *components, bit):
+        """.progressive(c, ..., bit: bit)"""
+        return cls([(c, 0, 0) for c in components], (0, 1), bit, 1)
+
+    @classmethod
+    def progressive_ac(cls, component, band, bits):
+        """.progressive((c, ac), band: lo ..< hi, bits: bits...)"""
+        return cls([(component[0], 0, component[1])], (max(band[0], 1), min(band[1], 64)), bits, 0)
+
+    @classmethod
+    def progressive_ac_refine(cls, component, band, bit):
+        """.progressive((c, ac), band: lo ..< hi, bit: bit)"""
+        return cls([(component[0], 0, component[1])], (max(band[0], 1), min(band[1], 64)), bit, 1)
+
+
 def _scan_array(scans):
-    """[(component index, dc selector, ac selector), ...] per scan -> jpeg_amd_scan[]
-    (the JPEG.Header.Scan.sequential(...) constructor, jpeg.swift:1655-1700)."""
+    """Scan objects, or plain [(plane index, dc selector, ac selector), ...] lists for
+    sequential scans -> jpeg_amd_scan[]."""
     arr = (_lib.Scan * len(scans))()
     for i, sc in enumerate(scans):
-        sc = sorted(sc)
-        arr[i].ncomponents = len(sc)
-        for j, (c, dc, ac) in enumerate(sc):
+        if not isinstance(sc, Scan):
+            sc = Scan.sequential(*sc)
+        arr[i].ncomponents = len(sc.components)
+        for j, (c, dc, ac) in enumerate(sc.components):
             arr[i].component[j], arr[i].dc[j], arr[i].ac[j] = c, dc, ac
+        arr[i].band_lo, arr[i].band_hi = sc.band
+        arr[i].bit, arr[i].refine = sc.bit, sc.refine
     return arr
 
 
-def _jfif(jfif):
-    """jfif: None or (version_minor, unit, density_x, density_y) -- JPEG.JFIF(version:density:)."""
-    if jfif is None:
-        return None
-    j = _lib.Jfif()
-    j.version_minor, j.unit, j.density_x, j.density_y = jfif
-    return j
+def _metadata_array(metadata):
+    """[("jfif", (version_minor, unit, density_x, density_y)) | ("comment", bytes) |
+    ("application", n, bytes), ...] -> (jpeg_amd_metadata[], keep-alive buffers) -- JPEG.Metadata."""
+    metadata = list(metadata or [])
+    arr = (_lib.Metadata * max(len(metadata), 1))()
+    keep = []
+    for i, m in enumerate(metadata):
+        if m[0] == "jfif":
+            arr[i].kind = 0
+            arr[i].jfif.version_minor, arr[i].jfif.unit, arr[i].jfif.density_x, arr[i].jfif.density_y = m[1]
+        else:
+            data = np.frombuffer(bytes(m[-1]), np.uint8).copy()
+            keep.append(data)
+            arr[i].kind, arr[i].app = (2, 0) if m[0] == "comment" else (1, int(m[1]))
+            arr[i].data, arr[i].size = data.ctypes.data, data.size
+    return arr, len(metadata), keep
 
 
 def _file_bytes(source) -> np.ndarray:
@@ -487,11 +532,11 @@ class Rectangular:
             "jpeg_amd_encode", ctx.handle)
         return Spectral(ctx, size, layout, out, tables, q)
 
-    def compress(self, quanta: Dict[int, Sequence[int]], scans, process: str = "baseline", jfif=None,
+    def compress(self, quanta: Dict[int, Sequence[int]], scans, process: str = "baseline", metadata=None,
                  path=None) -> bytes:
         """Rectangular.compress(stream:quanta:) / compress(path:quanta:) -- encode.swift:2031,
         os.swift:412: decomposed().fdct(quanta:).compress(...)."""
-        return self.decomposed().fdct(quanta).compress(scans, process=process, jfif=jfif, path=path)
+        return self.decomposed().fdct(quanta).compress(scans, process=process, metadata=metadata, path=path)
 
     def host_values(self) -> np.ndarray:
         return self.values.cpu().numpy().view(np.uint16)

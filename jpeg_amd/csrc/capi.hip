@@ -759,7 +759,7 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
 int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels,
                       jpeg_amd_color color, const int32_t *quanta_key, const uint16_t *h_quanta,
                       const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans,
-                      int nscans, const jpeg_amd_jfif *jfif, uint8_t *h_out, size_t capacity,
+                      int nscans, const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out, size_t capacity,
                       size_t *nbytes)
 {
     JA_TRY(bind(ctx));
@@ -791,7 +791,7 @@ int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8
     }
     JA_TRY(jpeg_amd_host_encode(ctx, &L, h_pixels, color, h_quanta, ntables, coef));
     return jpeg_amd_jpeg_encode_spectral(frame, quanta_key, coef, h_quanta, h_quanta_keys, ntables, scans, nscans,
-                                         jfif, h_out, capacity, nbytes);
+                                         metadata, nmetadata, h_out, capacity, nbytes);
 }
 
 }  // extern "C"

@@ -20,7 +20,10 @@
 //     lifetime                                                     :1936-1969, jpeg.swift:1383-1442
 // Where the reference iterates a Swift Dictionary (hash order, not reproducible) this file
 // uses ascending key order; the reference's committed files agree with that choice.
-// Sequential (baseline / extended Huffman) scans only; progressive encoding returns ENOSUP.
+// Progressive scans (encode.swift:1013-1206, 1386-1557): DC first pass / refinement, interleaved
+// or not; AC first pass with LAZY ZRLs (only in front of a nonzero coefficient, unlike the
+// sequential coder) and EOB runs of at most 4096 blocks; AC refinement with the correction
+// bits of already-nonzero coefficients riding behind the next run / ZRL / EOB symbol.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -256,22 +259,197 @@ void segment(std::vector<uint8_t> &o, uint8_t marker, const std::vector<uint8_t>
     o.insert(o.end(), body.begin(), body.end());
 }
 
+// ---- progressive scans -------------------------------------------------------------------
+struct Token {           // one Huffman symbol + its appended bits (+ correction bits)
+    uint8_t sym;
+    uint8_t ntail;
+    uint16_t tail;
+    uint32_t ref_begin, ref_end;   // range in the scan's correction-bit pool
+};
+
+inline int16_t toward_zero_shift(int16_t c, int a)   // sign * (|c| >> a)
+{
+    const int m = c < 0 ? -(int)c : (int)c;
+    return (int16_t)(c < 0 ? -(m >> a) : (m >> a));
+}
+
+void scan_header(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const int32_t *ids)
+{
+    std::vector<uint8_t> sos{(uint8_t)sc.ncomponents};
+    for (int j = 0; j < sc.ncomponents; ++j) {
+        sos.push_back((uint8_t)ids[sc.component[j]]);
+        sos.push_back((uint8_t)(sc.dc[j] << 4 | sc.ac[j]));
+    }
+    sos.push_back((uint8_t)sc.band_lo);
+    sos.push_back((uint8_t)(sc.band_hi - 1));
+    sos.push_back((uint8_t)((sc.refine ? sc.bit + 1 : 0) << 4 | sc.bit));
+    segment(out, 0xda, sos);
+}
+
+int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const std::vector<Plane> &planes,
+                     const int32_t *ids, int mcux, int mcuy)
+{
+    const int ns = sc.ncomponents, a = sc.bit;
+    // the blocks of the scan in coding order: (plane, x, y); slot j of the scan for table choice
+    auto for_each_block = [&](auto &&fn) {
+        if (ns == 1) {
+            const Plane &p = planes[sc.component[0]];
+            for (int y = 0; y < p.uy; ++y)
+                for (int x = 0; x < p.ux; ++x) fn(0, p.at(x, y));
+        } else {
+            for (int my = 0; my < mcuy; ++my)
+                for (int mx = 0; mx < mcux; ++mx)
+                    for (int j = 0; j < ns; ++j) {
+                        const Plane &p = planes[sc.component[j]];
+                        for (int by = 0; by < p.fy; ++by)
+                            for (int bx = 0; bx < p.fx; ++bx) fn(j, p.at(mx * p.fx + bx, my * p.fy + by));
+                    }
+        }
+    };
+
+    if (sc.band_lo == 0 && sc.refine) {          // DC refinement: one raw bit per block, no tables
+        scan_header(out, sc, ids);
+        Sink s; s.out = &out;
+        for_each_block([&](int, const int16_t *blk) { s.bits((unsigned)(blk[0] >> a) & 1u, 1); });
+        s.finish();
+        return JPEG_AMD_OK;
+    }
+    if (sc.band_lo == 0) {                       // DC first pass: differences of coef >> a
+        long freq[4][256];
+        std::memset(freq, 0, sizeof freq);
+        Codebook cb[4];
+        for (int pass = 0; pass < 2; ++pass) {
+            Sink s;
+            if (pass) s.out = &out;
+            int16_t pred[4] = {0, 0, 0, 0};
+            for_each_block([&](int j, const int16_t *blk) {
+                const int16_t high = (int16_t)(blk[0] >> a);
+                int binade; unsigned tail;
+                compact((int16_t)(high - pred[j]), binade, tail);
+                pred[j] = high;
+                if (pass) { s.bits(cb[sc.dc[j]].code[binade], cb[sc.dc[j]].length[binade]); s.bits(tail, binade); }
+                else ++freq[sc.dc[j]][binade];
+            });
+            if (pass) { s.finish(); break; }
+            bool used[4] = {false, false, false, false};
+            for (int j = 0; j < ns; ++j) used[sc.dc[j]] = true;
+            std::vector<uint8_t> dht;
+            for (int t = 0; t < 4; ++t)
+                if (used[t]) {
+                    if (!build_codebook(freq[t], cb[t])) return JPEG_AMD_EINVAL;
+                    dht.push_back((uint8_t)t);
+                    dht.insert(dht.end(), cb[t].counts, cb[t].counts + 16);
+                    dht.insert(dht.end(), cb[t].symbols.begin(), cb[t].symbols.end());
+                }
+            segment(out, 0xc4, dht);
+            scan_header(out, sc, ids);
+        }
+        return JPEG_AMD_OK;
+    }
+
+    // AC scans: one component, tokens first (their statistics define the table), bits second
+    std::vector<Token> tokens;
+    std::vector<uint8_t> pool;                   // correction bits of the refinement pass
+    auto eob = [&](uint32_t rb, uint32_t re) {   // extend the running EOB run or open a new one
+        if (!tokens.empty() && (tokens.back().sym & 0x0f) == 0 && tokens.back().sym != 0xf0) {
+            Token &t = tokens.back();
+            const unsigned count = (1u << (t.sym >> 4)) | t.tail;
+            if (count < 4096) {
+                const unsigned n = count + 1;
+                const int binade = 31 - __builtin_clz(n);
+                t.sym = (uint8_t)(binade << 4); t.ntail = (uint8_t)binade; t.tail = (uint16_t)(n & ~(1u << binade));
+                t.ref_end = re;                  // the pool is contiguous: this block's bits follow the run's
+                return;
+            }
+        }
+        tokens.push_back({0x00, 0, 0, rb, re});
+    };
+    const Plane &p = planes[sc.component[0]];
+    if (!sc.refine) {
+        for (int y = 0; y < p.uy; ++y)
+            for (int x = 0; x < p.ux; ++x) {
+                const int16_t *blk = p.at(x, y);
+                int zeroes = 0;
+                for (int z = sc.band_lo; z < sc.band_hi; ++z) {
+                    const int16_t high = toward_zero_shift(blk[z], a);
+                    if (high == 0) { ++zeroes; continue; }
+                    for (int k = 0; k < zeroes / 16; ++k) tokens.push_back({0xf0, 0, 0, 0, 0});
+                    int binade; unsigned tail;
+                    compact(high, binade, tail);
+                    tokens.push_back({(uint8_t)((zeroes % 16) << 4 | binade), (uint8_t)binade, (uint16_t)tail, 0, 0});
+                    zeroes = 0;
+                }
+                if (zeroes > 0) eob(0, 0);
+            }
+    } else {
+        const int mask = ~((1 << (a + 1)) - 1);
+        for (int y = 0; y < p.uy; ++y)
+            for (int x = 0; x < p.ux; ++x) {
+                const int16_t *blk = p.at(x, y);
+                int zeroes = 0;
+                // correction bits seen since the last symbol, cut into one chunk per completed
+                // run of 16 zeros (each chunk will ride behind its ZRL); `staged` = the open chunk
+                std::vector<uint32_t> cuts;               // pool positions where a chunk ends
+                const uint32_t block_begin = (uint32_t)pool.size();
+                uint32_t chunk_begin = block_begin;
+                for (int z = sc.band_lo; z < sc.band_hi; ++z) {
+                    const int c = blk[z], m = c < 0 ? -c : c;
+                    const int product = m & mask, remainder = m & ~mask;
+                    const int low = c < 0 ? -(remainder >> a) : (remainder >> a);
+                    if (product != 0) { pool.push_back(low != 0); continue; }   // already nonzero: correction bit
+                    if (low == 0) {
+                        ++zeroes;
+                        if (zeroes % 16 == 0) cuts.push_back((uint32_t)pool.size());
+                        continue;
+                    }
+                    // newly nonzero: pending ZRLs with their chunks, then the run symbol with the open chunk
+                    for (uint32_t cut : cuts) { tokens.push_back({0xf0, 0, 0, chunk_begin, cut}); chunk_begin = cut; }
+                    cuts.clear();
+                    tokens.push_back({(uint8_t)((zeroes % 16) << 4 | 1), 1, (uint16_t)(low > 0 ? 1 : 0), chunk_begin, (uint32_t)pool.size()});
+                    chunk_begin = (uint32_t)pool.size();
+                    zeroes = 0;
+                }
+                // end of band: everything not yet attached goes behind the EOB
+                if (zeroes > 0 || pool.size() > chunk_begin) eob(chunk_begin, (uint32_t)pool.size());
+            }
+    }
+    long freq[256];
+    std::memset(freq, 0, sizeof freq);
+    for (const Token &t : tokens) ++freq[t.sym];
+    Codebook cb;
+    if (!build_codebook(freq, cb)) return JPEG_AMD_EINVAL;
+    std::vector<uint8_t> dht{(uint8_t)(0x10 | sc.ac[0])};
+    dht.insert(dht.end(), cb.counts, cb.counts + 16);
+    dht.insert(dht.end(), cb.symbols.begin(), cb.symbols.end());
+    segment(out, 0xc4, dht);
+    scan_header(out, sc, ids);
+    Sink s; s.out = &out;
+    for (const Token &t : tokens) {
+        s.bits(cb.code[t.sym], cb.length[t.sym]);
+        s.bits(t.tail, t.ntail);
+        for (uint32_t r = t.ref_begin; r < t.ref_end; ++r) s.bits(pool[r], 1);
+    }
+    s.finish();
+    return JPEG_AMD_OK;
+}
+
 }  // namespace
 
 extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_t *quanta_key,
                                              const int16_t *const h_coef[], const uint16_t *h_quanta,
                                              const int32_t *h_quanta_keys, int ntables,
                                              const jpeg_amd_scan *scans, int nscans,
-                                             const jpeg_amd_jfif *jfif, uint8_t *h_out, size_t capacity,
-                                             size_t *nbytes)
+                                             const jpeg_amd_metadata *metadata, int nmetadata,
+                                             uint8_t *h_out, size_t capacity, size_t *nbytes)
 {
     if (!frame || !quanta_key || !h_coef || !h_quanta || !h_quanta_keys || !scans || !nbytes) return JPEG_AMD_EINVAL;
     const int nc = frame->ncomponents;
     if (nc < 1 || nc > JPEG_AMD_MAX_PLANES || nscans < 1 || ntables < 1) return JPEG_AMD_EINVAL;
     if (frame->width < 1 || frame->height < 1 || frame->width > 65535 || frame->height > 65535) return JPEG_AMD_EINVAL;
-    if (frame->process == 2) return JPEG_AMD_ENOSUP;             // progressive: not written yet
-    if (frame->process != 0 && frame->process != 1) return JPEG_AMD_EINVAL;
-    if (frame->precision != 8 && !(frame->process == 1 && frame->precision == 12)) return JPEG_AMD_EINVAL;
+    if (frame->process < 0 || frame->process > 2) return JPEG_AMD_EINVAL;
+    if (frame->precision != 8 && !(frame->process != 0 && frame->precision == 12)) return JPEG_AMD_EINVAL;
+    if (nmetadata < 0 || (nmetadata > 0 && !metadata)) return JPEG_AMD_EINVAL;
+    const bool progressive = frame->process == 2;
 
     std::vector<Plane> planes((size_t)nc);
     for (int c = 0; c < nc; ++c) {
@@ -297,6 +475,14 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
             volume += planes[c].fx * planes[c].fy;
         }
         if (sc.ncomponents > 1 && volume > 10) return JPEG_AMD_EINVAL;
+        const bool seq = sc.band_lo == 0 && sc.band_hi == 0 && sc.bit == 0 && sc.refine == 0;
+        if (progressive == seq) return JPEG_AMD_EINVAL;   // scan kind must match the process
+        if (progressive) {
+            if (sc.band_lo < 0 || sc.band_hi > 64 || sc.band_lo >= sc.band_hi || sc.bit < 0 || sc.bit > 13) return JPEG_AMD_EINVAL;
+            if (sc.band_lo == 0 && sc.band_hi != 1) return JPEG_AMD_EINVAL;          // DC and AC never share a scan
+            if (sc.band_lo > 0 && sc.ncomponents != 1) return JPEG_AMD_EINVAL;       // "progressive ac scan cannot be interleaved"
+            if (sc.refine != 0 && sc.refine != 1) return JPEG_AMD_EINVAL;
+        }
     }
 
     // ---- quantisation-table slots by lifetime, table definition groups ----
@@ -333,12 +519,19 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
     std::vector<uint8_t> out;
     out.reserve(capacity ? capacity : 1 << 16);
     out.push_back(0xff); out.push_back(0xd8);
-    if (jfif) {
-        if (jfif->version_minor < 0 || jfif->version_minor > 2 || jfif->unit < 0 || jfif->unit > 2) return JPEG_AMD_EINVAL;
-        std::vector<uint8_t> b{'J', 'F', 'I', 'F', 0, 1, (uint8_t)jfif->version_minor, (uint8_t)jfif->unit};
-        put16(b, (unsigned)jfif->density_x); put16(b, (unsigned)jfif->density_y);
-        b.push_back(0); b.push_back(0);
-        segment(out, 0xe0, b);
+    for (int m = 0; m < nmetadata; ++m) {
+        const jpeg_amd_metadata &md = metadata[m];
+        if (md.kind == 0) {
+            const jpeg_amd_jfif &j = md.jfif;
+            if (j.version_minor < 0 || j.version_minor > 2 || j.unit < 0 || j.unit > 2) return JPEG_AMD_EINVAL;
+            std::vector<uint8_t> b{'J', 'F', 'I', 'F', 0, 1, (uint8_t)j.version_minor, (uint8_t)j.unit};
+            put16(b, (unsigned)j.density_x); put16(b, (unsigned)j.density_y);
+            b.push_back(0); b.push_back(0);
+            segment(out, 0xe0, b);
+        } else if (md.kind == 1 || md.kind == 2) {
+            if ((md.size && !md.data) || md.size > 65533 || (md.kind == 1 && (md.app < 0 || md.app > 15))) return JPEG_AMD_EINVAL;
+            segment(out, md.kind == 1 ? (uint8_t)(0xe0 + md.app) : 0xfe, std::vector<uint8_t>(md.data, md.data + md.size));
+        } else return JPEG_AMD_EINVAL;
     }
     {
         std::vector<uint8_t> b{(uint8_t)frame->precision};
@@ -349,7 +542,7 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
             b.push_back((uint8_t)(planes[c].fx << 4 | planes[c].fy));
             b.push_back((uint8_t)life[(size_t)key_index(quanta_key[c])].slot);
         }
-        segment(out, frame->process == 0 ? 0xc0 : 0xc1, b);
+        segment(out, frame->process == 0 ? 0xc0 : frame->process == 1 ? 0xc1 : 0xc2, b);
     }
     int scale_x = 1, scale_y = 1;                // Layout.scale: max factor over the components
     for (const Plane &p : planes) { scale_x = std::max(scale_x, p.fx); scale_y = std::max(scale_y, p.fy); }
@@ -378,6 +571,11 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
         for (int i = starts[g]; i < end; ++i) {
             const jpeg_amd_scan &sc = scans[i];
             const int ns = sc.ncomponents;
+            if (progressive) {
+                const int st = progressive_scan(out, sc, planes, frame->id, mcux, mcuy);
+                if (st != JPEG_AMD_OK) return st;
+                continue;
+            }
             // pass 1: symbol statistics per table selector
             long dc_freq[4][256], ac_freq[4][256];
             std::memset(dc_freq, 0, sizeof dc_freq);

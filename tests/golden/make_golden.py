@@ -147,6 +147,18 @@ def main():
         "source": "encode/" + stem + ".rgb", "source_sha256": sha_file(os.path.join(enc, stem + ".rgb")),
         "origin": "examples/encode-basic/" + stem + ".rgb", "size": [400, 665], "cases": cases}
 
+    # ---- files the reference's WRITER produced with other scan progressions (pins for the host
+    #      entropy encoder: progressive first / refinement scans, EOB runs, comment segments) ----
+    written = []
+    for origin in ["examples/encode-advanced/karlie-cfdas-2011.png.rgb.jpg",      # 11 progressive scans, COM
+                   "examples/recompress/recompressed-requantized.jpg",            # progressive, bits 0..., JFIF
+                   "examples/in-memory/karlie-2011.jpg.jpg"]:
+        fn = os.path.basename(origin)
+        copy(os.path.join(REF, origin), os.path.join(HERE, "encode", fn))
+        written.append({"file": "encode/" + fn, "origin": origin, "file_sha256": sha_file(os.path.join(REF, origin)),
+                        "file_nbytes": os.path.getsize(os.path.join(REF, origin))})
+    manifest["encode"]["written_by_reference"] = written
+
     # ---- attribution ----------------------------------------------------------------------
     with open(os.path.join(HERE, "ATTRIBUTION.md"), "w") as f:
         f.write("# Image fixtures: attribution\n\n"

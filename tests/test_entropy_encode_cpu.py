@@ -13,11 +13,11 @@ import pytest
 
 import _golden as G
 from jpeg_amd import _lib
-from jpeg_amd.api import _scan_array, _jfif
+from jpeg_amd.api import Scan, _scan_array, _metadata_array
 
 # examples/encode-basic/main.swift: scan 1 = Y with tables (0, 0); scan 2 = Cb, Cr with (1, 1)
 SCANS = [[(0, 0, 0)], [(1, 1, 1), (2, 1, 1)]]
-JFIF = (2, 2, 1, 1)            # JPEG.JFIF(version: .v1_2, density: (1, 1, .centimeters))
+JFIF = [("jfif", (2, 2, 1, 1))]            # JPEG.JFIF(version: .v1_2, density: (1, 1, .centimeters))
 
 
 def _decode(path):
@@ -32,16 +32,16 @@ def _decode(path):
     return data, info, planes, quanta
 
 
-def _encode(info, planes, keys, tables, tkeys, scans=SCANS, jfif=JFIF):
+def _encode(info, planes, keys, tables, tkeys, scans=SCANS, metadata=JFIF):
     lib = _lib.lib()
     qkey = (C.c_int32 * len(keys))(*keys)
     tk = (C.c_int32 * len(tkeys))(*tkeys)
     tables = np.ascontiguousarray(tables, np.uint16)
     sarr = _scan_array(scans)
-    j = _jfif(jfif)
+    marr, nmeta, _keep = _metadata_array(metadata)
     n = C.c_size_t()
     args = [C.byref(info), qkey, _lib.ptr_array([p.ctypes.data for p in planes]), tables.ctypes.data, tk, len(tkeys),
-            sarr, len(scans), C.byref(j) if j is not None else None]
+            sarr, len(scans), marr, nmeta]
     st = lib.jpeg_amd_jpeg_encode_spectral(*args, None, 0, C.byref(n))
     if st != 0:
         return st, None
@@ -68,7 +68,7 @@ def test_round_trip_through_the_decoder_for_other_scan_structures():
     for process, scans in ((0, [[(0, 0, 0), (1, 1, 1), (2, 1, 1)]]),
                            (1, [[(0, 0, 0)], [(1, 1, 2)], [(2, 3, 3)]])):
         info.process = process
-        st, out = _encode(info, planes, [0, 1, 1], np.stack([quanta[0], quanta[1]]), [0, 1], scans=scans, jfif=None)
+        st, out = _encode(info, planes, [0, 1, 1], np.stack([quanta[0], quanta[1]]), [0, 1], scans=scans, metadata=None)
         assert st == 0
         lib = _lib.lib()
         info2 = _lib.FrameInfo()
@@ -94,7 +94,7 @@ def test_long_zero_runs_follow_the_reference_rule():
         blk = np.zeros((1, 1, 64), np.int16)
         blk[0, 0, 0] = 5
         blk[0, 0, 1:last + 1] = -3          # no zero before `last`: only the trailing run counts
-        st, out = _encode(info, [blk], [0], q, [0], scans=[[(0, 0, 0)]], jfif=None)
+        st, out = _encode(info, [blk], [0], q, [0], scans=[[(0, 0, 0)]], metadata=None)
         assert st == 0
         back = np.zeros_like(blk)
         q2 = np.zeros((4, 64), np.uint16)
@@ -115,4 +115,98 @@ def test_precondition_failures():
     assert _encode(info, planes, [0, 7, 1], tables, [0, 1])[0] == _lib.EINVAL          # missing quantization table
     assert _encode(info, planes, [0, 1, 1], tables, [0, 1], scans=[[(0, 2, 0)]])[0] == _lib.EINVAL   # baseline: selectors 0..1
     info.process = 2
-    assert _encode(info, planes, [0, 1, 1], tables, [0, 1])[0] == _lib.ENOSUP           # progressive not written
+    assert _encode(info, planes, [0, 1, 1], tables, [0, 1])[0] == _lib.EINVAL           # sequential scans in a progressive frame
+    ac2 = [Scan.progressive_dc((0, 0), (1, 1), (2, 1), bits=0), Scan(((0, 0, 0), (1, 0, 0)), (1, 64), 0, 0)]
+    assert _encode(info, planes, [0, 1, 1], tables, [0, 1], scans=ac2)[0] == _lib.EINVAL  # "progressive ac scan cannot be interleaved"
+
+
+# ---- any file the reference's writer produced: read its scan script back and re-encode ----------
+def _script(data):
+    """Walk the markers of a JPEG file: metadata segments in front of the frame header, the scan
+    progression (as Scan objects over plane indices), and one quantisation key per DQT table
+    definition (a component's key = the definition its frame selector points at when its first
+    scan starts -- the inverse of JPEG.Layout's slot allocation, jpeg.swift:1383-1442)."""
+    b = bytes(data)
+    i, metadata, scans, ids, tq = 2, [], [], [], []
+    slot_key, nkeys, comp_key, tables = {}, 0, {}, {}
+    process = None
+    while i < len(b):
+        assert b[i] == 0xff
+        m = b[i + 1]
+        if m == 0xd9:
+            break
+        n = b[i + 2] << 8 | b[i + 3]
+        body = b[i + 4:i + 2 + n]
+        if process is None and (0xe0 <= m <= 0xef or m == 0xfe):
+            metadata.append(("comment", body) if m == 0xfe else ("application", m - 0xe0, body))
+        elif m in (0xc0, 0xc1, 0xc2):
+            process = m - 0xc0
+            for c in range(body[5]):
+                ids.append(body[6 + 3 * c]); tq.append(body[8 + 3 * c])
+        elif m == 0xdb:
+            j = 0
+            while j < len(body):
+                wide, slot = body[j] >> 4, body[j] & 15
+                vals = (np.frombuffer(body[j + 1:j + 129], ">u2") if wide else np.frombuffer(body[j + 1:j + 65], np.uint8)).astype(np.uint16)
+                slot_key[slot] = nkeys; tables[nkeys] = vals; nkeys += 1
+                j += 129 if wide else 65
+        elif m == 0xda:
+            ns = body[0]
+            comps = [(ids.index(body[1 + 2 * k]), body[2 + 2 * k] >> 4, body[2 + 2 * k] & 15) for k in range(ns)]
+            ss, se, ah, al = body[1 + 2 * ns], body[2 + 2 * ns], body[3 + 2 * ns] >> 4, body[3 + 2 * ns] & 15
+            for c, _, _ in comps:
+                comp_key.setdefault(c, slot_key[tq[c]])
+            scans.append(Scan(comps) if process != 2 else Scan(comps, (ss, se + 1), al, 1 if ah else 0))
+            i += 2 + n
+            while not (b[i] == 0xff and b[i + 1] != 0 and not 0xd0 <= b[i + 1] <= 0xd7):
+                i += 1
+            continue
+        i += 2 + n
+    keys = [comp_key[c] for c in range(len(ids))]
+    tkeys = sorted(set(keys))
+    return process, metadata, scans, keys, tkeys, np.stack([tables[k] for k in tkeys])
+
+
+@pytest.mark.parametrize("entry", G.manifest()["encode"]["written_by_reference"] +
+                         [c for c in G.encode_cases() if "file" in c][:2], ids=lambda e: e["file"].split("/")[-1])
+def test_files_written_by_the_reference_reencode_byte_for_byte(entry):
+    """Progressive DC / AC first passes and refinements with EOB runs (examples/encode-advanced,
+    11 scans + a comment segment), spectral-selection-only progressions (examples/recompress),
+    and the original file's own progression (examples/in-memory)."""
+    data, info, planes, quanta = _decode(G.path(entry["file"]))
+    process, metadata, scans, keys, tkeys, tables = _script(data)
+    assert info.process == process
+    st, out = _encode(info, planes, keys, tables, tkeys, scans=scans, metadata=metadata)
+    assert st == 0
+    if hashlib.sha256(out.tobytes()).hexdigest() != entry["file_sha256"]:
+        # The reference serialises the tables of one DHT segment in the iteration order of a Swift
+        # Dictionary (encode.swift:1324-1328, 1467-1470), i.e. in per-process hash order; this
+        # library writes them in ascending selector order.  Identical up to that order:
+        assert _sorted_dht(out.tobytes()) == _sorted_dht(bytes(data))
+        assert out.size == data.size
+
+
+def _sorted_dht(b):
+    """The file with the tables inside every DHT segment sorted by (class, selector)."""
+    out, i = bytearray(b[:2]), 2
+    while i < len(b):
+        m = b[i + 1]
+        if m == 0xd9:
+            out += b[i:]
+            break
+        n = b[i + 2] << 8 | b[i + 3]
+        body = b[i + 4:i + 2 + n]
+        if m == 0xc4:
+            tabs, j = [], 0
+            while j < len(body):
+                k = 17 + sum(body[j + 1:j + 17])
+                tabs.append(body[j:j + k]); j += k
+            body = b"".join(sorted(tabs, key=lambda t: t[0]))
+        out += b[i:i + 4] + body
+        i += 2 + n
+        if m == 0xda:
+            j = i
+            while not (b[j] == 0xff and b[j + 1] != 0 and not 0xd0 <= b[j + 1] <= 0xd7):
+                j += 1
+            out += b[i:j]; i = j
+    return bytes(out)

@@ -9,12 +9,12 @@ import pytest
 
 import _golden as G
 from jpeg_amd import _lib
-from jpeg_amd.api import _scan_array, _jfif
+from jpeg_amd.api import _scan_array, _metadata_array
 
 pytestmark = pytest.mark.gpu
 
 SCANS = [[(0, 0, 0)], [(1, 1, 1), (2, 1, 1)]]      # examples/encode-basic/main.swift:42-46
-JFIF = (2, 2, 1, 1)                                # .init(version: .v1_2, density: (1, 1, .centimeters))
+JFIF = [("jfif", (2, 2, 1, 1))]                                # .init(version: .v1_2, density: (1, 1, .centimeters))
 
 
 @pytest.fixture(scope="module")
@@ -40,11 +40,12 @@ def test_compress_reproduces_the_references_file(ctx, case):
     assert [t.tolist() for t in tables] == case["quanta_zigzag"][:2]
     qkey = (C.c_int32 * 3)(0, 1, 1)
     tk = (C.c_int32 * 2)(0, 1)
-    sarr, j, n = _scan_array(SCANS), _jfif(JFIF), C.c_size_t()
+    sarr, n = _scan_array(SCANS), C.c_size_t()
+    marr, nmeta, _keep = _metadata_array(JFIF)
     out = np.empty(1 << 20, np.uint8)
     px = np.ascontiguousarray(rgb)
     st = _lib.lib().jpeg_amd_compress(ctx.handle, C.byref(info), px.ctypes.data, J.RGB.code, qkey, tables.ctypes.data,
-                                      tk, 2, sarr, 2, C.byref(j), out.ctypes.data, out.size, C.byref(n))
+                                      tk, 2, sarr, 2, marr, nmeta, out.ctypes.data, out.size, C.byref(n))
     assert st == 0, st
     assert [[info.units_x[c], info.units_y[c]] for c in range(3)] == case["units"]
     got = out[:n.value]
@@ -64,9 +65,36 @@ def test_python_mirror_compress_then_decompress(ctx, mode, tmp_path):
     layout = J.Layout("ycc8", {1: (tuple(case["factors"][0]), 0), 2: ((1, 1), 1), 3: ((1, 1), 1)})
     quanta = {0: J.compression_quanta("luminance", 1.0), 1: J.compression_quanta("chrominance", 1.0)}
     path = str(tmp_path / "out.jpg")
-    data = J.Rectangular.pack(ctx, size, layout, rgb, J.RGB).compress(quanta, SCANS, jfif=JFIF, path=path)
+    data = J.Rectangular.pack(ctx, size, layout, rgb, J.RGB).compress(quanta, SCANS, metadata=JFIF, path=path)
     assert hashlib.sha256(data).hexdigest() == case["file_sha256"]
     back = J.Rectangular.decompress(ctx, path).unpack(J.RGB).cpu().numpy()
     err = back.astype(np.int32) - rgb.astype(np.int32)
     psnr = 10 * np.log10(255.0 ** 2 / np.mean(err.astype(np.float64) ** 2))
     assert psnr > 25.0, psnr
+
+
+def test_progressive_compress_round_trip(ctx, tmp_path):
+    """examples/encode-advanced's progression (successive approximation, refinement scans, a
+    comment record) on the GPU-encoded coefficients: the written file must decode back to exactly
+    those coefficients (through this library's own progressive decoder, which is pinned by the
+    reference's progressive golds)."""
+    import jpeg_amd as J
+    from jpeg_amd.api import Scan
+    rgb, size = G.encode_source()
+    layout = J.Layout("ycc8", {1: ((2, 1), 0), 2: ((1, 1), 1), 3: ((1, 1), 1)})
+    quanta = {0: [1, 2, 2, 3, 3, 3] + [4] * 58, 1: [1, 2, 2, 5, 5, 5] + [30] * 58}
+    Y, Cb, Cr = 0, 1, 2
+    scans = [Scan.progressive_dc((Y, 0), (Cb, 1), (Cr, 1), bits=2),
+             Scan.progressive_dc_refine(Y, Cb, Cr, bit=1), Scan.progressive_dc_refine(Y, Cb, Cr, bit=0),
+             Scan.progressive_ac((Y, 0), (1, 64), bits=1),
+             Scan.progressive_ac((Cb, 0), (1, 6), bits=1), Scan.progressive_ac((Cr, 0), (1, 6), bits=1),
+             Scan.progressive_ac((Cb, 0), (6, 64), bits=1), Scan.progressive_ac((Cr, 0), (6, 64), bits=1),
+             Scan.progressive_ac_refine((Y, 0), (1, 64), bit=0),
+             Scan.progressive_ac_refine((Cb, 0), (1, 64), bit=0), Scan.progressive_ac_refine((Cr, 0), (1, 64), bit=0)]
+    spectral = J.Rectangular.pack(ctx, size, layout, rgb, J.RGB).decomposed().fdct(quanta)
+    data = spectral.compress(scans, process="progressive", metadata=[("comment", b"the way u say 'important' is important")])
+    back = J.Spectral.decompress(ctx, data)
+    assert J.inspect(data).nscans == 11 and J.inspect(data).process == 2
+    for a, b in zip(spectral.host_planes(), back.host_planes()):
+        assert (a == b).all()
+    assert all((np.asarray(x) == np.asarray(y)).all() for x, y in zip(back.quanta, [quanta[0], quanta[1], quanta[1]]))

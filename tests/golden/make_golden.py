@@ -152,8 +152,9 @@ def main():
     written = []
     for origin in ["examples/encode-advanced/karlie-cfdas-2011.png.rgb.jpg",      # 11 progressive scans, COM
                    "examples/recompress/recompressed-requantized.jpg",            # progressive, bits 0..., JFIF
-                   "examples/in-memory/karlie-2011.jpg.jpg"]:
-        fn = os.path.basename(origin)
+                   "examples/in-memory/karlie-2011.jpg.jpg",
+                   "examples/custom-color/output.jpg"]:                           # 12-bit, 4 components, 16-bit DQT
+        fn = os.path.basename(origin) if "custom-color" not in origin else "custom-color-output.jpg"
         copy(os.path.join(REF, origin), os.path.join(HERE, "encode", fn))
         written.append({"file": "encode/" + fn, "origin": origin, "file_sha256": sha_file(os.path.join(REF, origin)),
                         "file_nbytes": os.path.getsize(os.path.join(REF, origin))})

@@ -60,3 +60,38 @@ def test_garbage_and_truncation_are_errors_not_crashes():
         part = np.ascontiguousarray(data[:cut])
         st = lib.jpeg_amd_jpeg_inspect(part.ctypes.data, part.size, C.byref(info))
         assert st in (0, _lib.EINVAL, _lib.ENOSUP)
+
+
+def test_corrupted_files_never_crash_the_decoder():
+    """The reference has a fuzz target for its decoder (tests/fuzz); here: 300 fixtures with
+    random byte flips, deletions and truncations, decoded in a child process -- any status is
+    fine, a signal is not."""
+    import subprocess, sys, textwrap, os
+    code = textwrap.dedent('''
+        import sys, ctypes as C, numpy as np
+        sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+        import _golden as G
+        from jpeg_amd import _lib
+        lib = _lib.lib()
+        rng = np.random.default_rng(20240807)
+        names = G.decode_names()
+        for it in range(300):
+            data = np.fromfile(G.path(G.entry(names[rng.integers(len(names))])["file"]), np.uint8).copy()
+            for _ in range(rng.integers(1, 8)):
+                mode, pos = rng.integers(3), rng.integers(2, data.size)
+                if mode == 0: data[pos] = rng.integers(256)
+                elif mode == 1: data = np.delete(data, slice(pos, pos + rng.integers(1, 64)))
+                else: data = data[:pos].copy()
+                if data.size < 4: break
+            data = np.ascontiguousarray(data)
+            info = _lib.FrameInfo()
+            st = lib.jpeg_amd_jpeg_inspect(data.ctypes.data, data.size, C.byref(info))
+            if st == 0 and info.units_x[0] * info.units_y[0] < 1 << 20:
+                planes = [np.zeros((max(info.units_y[c], 1), max(info.units_x[c], 1), 64), np.int16) for c in range(info.ncomponents)]
+                q = np.zeros((4, 64), np.uint16)
+                lib.jpeg_amd_jpeg_decode_spectral(data.ctypes.data, data.size, _lib.ptr_array([p.ctypes.data for p in planes]), q.ctypes.data, None)
+        print("survived")
+    ''')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stderr[-500:])

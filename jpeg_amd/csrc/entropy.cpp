@@ -167,6 +167,34 @@ struct Decoder {
         }
         return JPEG_AMD_OK;
     }
+    // Height 0 in the frame header: the real height follows the FIRST scan in a DNL segment
+    // (T.81 B.2.5; JPEG.Header.HeightRedefinition, decode.swift:837-860, Context.push(height:)).
+    // The planes are sized before that scan is decoded, so the DNL is looked up ahead of time.
+    int height_from_dnl(size_t pos) const
+    {
+        while (pos + 3 < n) {
+            if (data[pos] != 0xff) return 0;
+            const int m = data[pos + 1];
+            if (m == 0xff) { ++pos; continue; }
+            if (m == 0xd9) return 0;
+            const size_t seglen = ((size_t)data[pos + 2] << 8) | data[pos + 3];
+            if (seglen < 2 || pos + 2 + seglen > n) return 0;
+            if (m != 0xda) { pos += 2 + seglen; continue; }
+            size_t e = pos + 2 + seglen;                 // entropy-coded segment of the first scan
+            while (e + 1 < n) {
+                if (data[e] != 0xff) { ++e; continue; }
+                const int k = data[e + 1];
+                if (k == 0x00 || (k >= 0xd0 && k <= 0xd7)) { e += 2; continue; }
+                if (k == 0xff) { ++e; continue; }
+                break;
+            }
+            if (e + 5 < n && data[e + 1] == 0xdc && data[e + 2] == 0 && data[e + 3] == 4)
+                return (data[e + 4] << 8) | data[e + 5];
+            return 0;
+        }
+        return 0;
+    }
+
     int parse_sof(int marker, const uint8_t *s, size_t len)
     {
         if (len < 6) return JPEG_AMD_EINVAL;
@@ -176,7 +204,8 @@ struct Decoder {
         info.width = (s[3] << 8) | s[4];
         const int nc = s[5];
         if (nc < 1 || nc > JPEG_AMD_MAX_PLANES || len < 6 + 3 * (size_t)nc) return JPEG_AMD_ENOSUP;
-        if (info.width <= 0 || info.height <= 0) return JPEG_AMD_ENOSUP;   // DNL-defined heights: not supported
+        if (info.height == 0) info.height = height_from_dnl((size_t)(s + len - data));
+        if (info.width <= 0 || info.height <= 0) return JPEG_AMD_EINVAL;
         info.ncomponents = nc;
         comps.assign((size_t)nc, Component());
         int sx = 0, sy = 0;
@@ -425,7 +454,7 @@ struct Decoder {
                     pos = e;
                     break;
                 }
-                default: break;                                           // APPn, COM, DNL, ...: skipped
+                default: break;                                           // APPn, COM, ...: skipped; DNL: see parse_sof
             }
             if (st != JPEG_AMD_OK) return st;
         }

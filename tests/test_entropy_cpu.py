@@ -95,3 +95,25 @@ def test_corrupted_files_never_crash_the_decoder():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stderr[-500:])
+
+
+def test_height_defined_by_a_dnl_segment():
+    """Frame header with height 0 and a DNL segment after the first scan (T.81 B.2.5; the
+    reference: JPEG.Header.HeightRedefinition, Context.push(height:))."""
+    e = G.entry("color-sequential-1.jpg")
+    data = bytearray(np.fromfile(G.path(e["file"]), np.uint8).tobytes())
+    assert e["scans"] == 1
+    sof = data.index(b"\xff\xc0")
+    height = data[sof + 5] << 8 | data[sof + 6]
+    data[sof + 5:sof + 7] = b"\x00\x00"
+    eoi = data.rindex(b"\xff\xd9")
+    data[eoi:eoi] = b"\xff\xdc\x00\x04" + bytes([height >> 8, height & 255])
+    import tempfile, os
+    with tempfile.NamedTemporaryFile(suffix=".jpg", delete=False) as f:
+        f.write(bytes(data))
+    try:
+        info, planes, quanta = _decode(f.name)
+    finally:
+        os.unlink(f.name)
+    assert (info.width, info.height) == (e["width"], e["height"])
+    assert [G.sha(p) for p in planes] == e["coef_sha256"]

@@ -379,6 +379,41 @@ def extras(J, ctx, d_quanta, q_np, sync, args):
         out["c5_batch_128x1080p"] = {"ms": round(ms, 4), "Mpixels_per_s": round(wl.pixels / ms / 1e3, 1),
                                      "GB_per_s": round(wl.bytes / ms / 1e6, 1),
                                      "frac_hbm": round(wl.bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    # File path, PCIe inclusive (never the headline `value`): 1080p 4:2:0 baseline JPEG bytes in host
+    # memory -> RGB bytes in host memory; host threads entropy-decode while the device works on
+    # the previous chunk (jpeg_amd_decompress_batch).  The files come from this library's encoder.
+    try:
+        W, H = 1920, 1080
+        yy, xx = np.mgrid[0:H, 0:W]
+        rng = np.random.default_rng(5)
+        layout = J.Layout("ycc8", {1: ((2, 2), 0), 2: ((1, 1), 1), 3: ((1, 1), 1)})
+        quanta = {0: q_np[0], 1: q_np[1]}
+        files = []
+        for i in range(4):
+            base = 128 + 70 * np.sin(xx / (40.0 + 7 * i)) * np.cos(yy / (29.0 + 3 * i))
+            rgb = np.clip(base[..., None] + rng.integers(-12, 13, (H, W, 3)), 0, 255).astype(np.uint8).reshape(-1, 3)
+            data = J.Rectangular.pack(ctx, (W, H), layout, rgb, J.RGB).compress(
+                quanta, [[(0, 0, 0)], [(1, 1, 1), (2, 1, 1)]], metadata=[("jfif", (2, 2, 1, 1))])
+            files.append(np.frombuffer(data, np.uint8).copy())
+        n = 128
+        batch = [files[i % 4] for i in range(n)]
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in batch])
+        sizes = (C.c_size_t * n)(*[f.size for f in batch])
+        pixels = np.empty((n, W * H * 3), np.uint8)
+        threads = min(32, os.cpu_count() or 1)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            st = lib.jpeg_amd_decompress_batch(ctx.handle, ptrs, sizes, n, threads, 0, _lib.COLOR_RGB8, pixels.ctypes.data, 0, None)
+            dt = time.perf_counter() - t0
+            assert st == 0, st
+            best = dt if best is None else min(best, dt)
+        out["file_path_1080p_pcie_inclusive"] = {
+            "files": n, "host_threads": threads, "ms": round(best * 1e3, 2), "images_per_s": round(n / best, 1),
+            "Mpixels_per_s": round(n * W * H / best / 1e6, 1), "jpeg_MB_per_s": round(sum(f.size for f in batch) / best / 1e6, 1),
+            "note": "host Huffman decode + H2D + fused decode + D2H; bounded by PCIe and the host, not by the kernels"}
+    except Exception as e:
+        out["file_path_1080p_pcie_inclusive"] = {"error": repr(e)}
     return out
 
 

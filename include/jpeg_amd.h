@@ -221,6 +221,14 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
                         jpeg_amd_color color, uint8_t *h_pixels, size_t pixel_capacity,
                         jpeg_amd_frame_info *info);
 
+/* The same for n_images files of ONE frame geometry (a burst, the frames of an MJPEG stream):
+ * `nthreads` host threads (<= 0: all cores) entropy-decode into pinned buffers, the device decodes
+ * a chunk of images per launch.  h_pixels: image i at h_pixels + i * pixel_stride (0 = W*H*3).
+ * This is the restart-interval / image-level parallelism of SURVEY.md 8f-1 on the host side. */
+int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[],
+                              int n_images, int nthreads, int cosited, jpeg_amd_color color,
+                              uint8_t *h_pixels, size_t pixel_stride, jpeg_amd_frame_info *info);
+
 /* ---- host side of the path's OUTPUT ("next" row) ------------------------------
  * The Huffman entropy encoder and file writer behind JPEG.Data.Spectral.compress(stream:)
  * (encode.swift:1918-1972): optimised Huffman tables per scan (:700-760), sequential scans,

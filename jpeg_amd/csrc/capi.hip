@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "kernels.hpp"
@@ -25,6 +26,12 @@ struct jpeg_amd_ctx {
     uint16_t *d_qstage = nullptr;  // ring of staged host tables
     int qslot = 0;
     int last_hip = 0;
+    // staging of jpeg_amd_decompress_batch, kept between calls: two pinned host slots (the host
+    // threads fill one while the device works from the other) and one device slot
+    void *file_pinned[2] = {nullptr, nullptr};
+    void *file_device = nullptr;
+    size_t file_pinned_bytes = 0, file_device_bytes = 0;
+    hipEvent_t file_done[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -189,6 +196,11 @@ int jpeg_amd_ctx_destroy(jpeg_amd_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_qstage) (void)hipFree(ctx->d_qstage);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->file_pinned[i]) (void)hipHostFree(ctx->file_pinned[i]);
+        if (ctx->file_done[i]) (void)hipEventDestroy(ctx->file_done[i]);
+    }
+    if (ctx->file_device) (void)hipFree(ctx->file_device);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -753,6 +765,128 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
         L.qi[c] = c;
     }
     return jpeg_amd_host_decode(ctx, &L, coef, &quanta[0][0], fi.ncomponents, cosited, color, h_pixels);
+}
+
+// ---- many JPEG files of one geometry -> pixels: host threads entropy-decode a chunk into
+//      pinned memory while the device (H2D, fused decode, D2H on the context's stream) works on
+//      the previous chunk ----------------------------------------------------------------------
+int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[],
+                              int n_images, int nthreads, int cosited, jpeg_amd_color color,
+                              uint8_t *h_pixels, size_t pixel_stride, jpeg_amd_frame_info *info_out)
+{
+    JA_TRY(bind(ctx));
+    if (!h_jpeg || !nbytes || !h_pixels || n_images < 0) return JPEG_AMD_EINVAL;
+    if (n_images == 0) return JPEG_AMD_OK;
+    if (!h_jpeg[0]) return JPEG_AMD_EINVAL;
+    jpeg_amd_frame_info fi;
+    JA_TRY(jpeg_amd_jpeg_inspect(h_jpeg[0], nbytes[0], &fi));
+    if (info_out) *info_out = fi;
+    if (fi.precision != 8 || (fi.ncomponents != 1 && fi.ncomponents != 3)) return JPEG_AMD_ENOSUP;
+    const int nc = fi.ncomponents;
+    const size_t npx = (size_t)fi.width * fi.height * 3;
+    if (pixel_stride == 0) pixel_stride = npx;
+    if (pixel_stride < npx) return JPEG_AMD_EINVAL;
+
+    jpeg_amd_layout L{};
+    L.width = fi.width; L.height = fi.height; L.precision = 8; L.nplanes = nc;
+    L.scale_x = fi.scale_x; L.scale_y = fi.scale_y;
+    size_t plane[JPEG_AMD_MAX_PLANES] = {};
+    size_t coef_off[JPEG_AMD_MAX_PLANES] = {};
+    const int chunk = std::min(n_images, 32);
+    for (int c = 0; c < nc; ++c) {
+        L.factor_x[c] = fi.factor_x[c]; L.factor_y[c] = fi.factor_y[c];
+        L.units_x[c] = fi.units_x[c];   L.units_y[c] = fi.units_y[c];
+        L.qi[c] = c;
+        plane[c] = (size_t)64 * fi.units_x[c] * fi.units_y[c];
+    }
+    // slot layout: [coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk][quanta x chunk][pixels x chunk]
+    size_t off = 0;
+    for (int c = 0; c < nc; ++c) { coef_off[c] = off; off += align256(plane[c] * 2 * chunk); }
+    const size_t quanta_off = off;  off += align256((size_t)chunk * kQSlotElems * 2);
+    const size_t px_off = off;      off += align256(npx * chunk);
+    const size_t slot_bytes = off;
+    if (ctx->file_pinned_bytes < slot_bytes) {
+        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->file_pinned[i]) { (void)hipHostFree(ctx->file_pinned[i]); ctx->file_pinned[i] = nullptr; }
+            ctx->file_pinned_bytes = 0;
+            JA_HIP(ctx, hipHostMalloc(&ctx->file_pinned[i], slot_bytes, hipHostMallocDefault));
+            if (!ctx->file_done[i]) JA_HIP(ctx, hipEventCreateWithFlags(&ctx->file_done[i], hipEventDisableTiming));
+        }
+        ctx->file_pinned_bytes = slot_bytes;
+    }
+    if (ctx->file_device_bytes < slot_bytes) {
+        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->file_device) { (void)hipFree(ctx->file_device); ctx->file_device = nullptr; ctx->file_device_bytes = 0; }
+        JA_HIP(ctx, hipMalloc(&ctx->file_device, slot_bytes));
+        ctx->file_device_bytes = slot_bytes;
+    }
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    nthreads = std::max(1, std::min(nthreads, chunk));
+
+    char *dev = static_cast<char *>(ctx->file_device);
+    const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<const int16_t *>(dev + coef_off[c]);
+
+    // run `fn(i)` for i in [0, m) on the pool (the calling thread takes a share)
+    auto parallel = [&](int m, auto &&fn) {
+        const int t_n = std::min(nthreads, m);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < t_n; ++t) pool.emplace_back([&, t] { for (int i = t; i < m; i += t_n) fn(i); });
+        for (int i = 0; i < m; i += t_n) fn(i);
+        for (std::thread &th : pool) th.join();
+    };
+
+    const int nchunks = (n_images + chunk - 1) / chunk;
+    int result = JPEG_AMD_OK;
+    auto drain = [&](int k) -> int {                         // chunk k is on its way back: copy it out
+        const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
+        JA_HIP(ctx, hipEventSynchronize(ctx->file_done[slot]));
+        const uint8_t *src = static_cast<const uint8_t *>(ctx->file_pinned[slot]) + px_off;
+        parallel(m, [&](int i) { std::memcpy(h_pixels + (size_t)(base + i) * pixel_stride, src + npx * i, npx); });
+        return JPEG_AMD_OK;
+    };
+    for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
+        const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
+        char *host = static_cast<char *>(ctx->file_pinned[slot]);
+        // slot `slot` was last used by chunk k - 2, which drain(k - 2) has already waited for
+        std::vector<int> status((size_t)m, JPEG_AMD_OK);
+        parallel(m, [&](int i) {
+            int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
+            for (int c = 0; c < nc; ++c) planes[c] = reinterpret_cast<int16_t *>(host + coef_off[c]) + plane[c] * i;
+            jpeg_amd_frame_info f{};
+            if (!h_jpeg[base + i]) { status[i] = JPEG_AMD_EINVAL; return; }
+            // geometry first: the planes are sized for image 0
+            int st = jpeg_amd_jpeg_inspect(h_jpeg[base + i], nbytes[base + i], &f);
+            if (st == JPEG_AMD_OK) {
+                bool same = f.width == fi.width && f.height == fi.height && f.precision == 8 && f.ncomponents == nc;
+                for (int c = 0; same && c < nc; ++c)
+                    same = f.factor_x[c] == fi.factor_x[c] && f.factor_y[c] == fi.factor_y[c];
+                if (!same) st = JPEG_AMD_EINVAL;             // one geometry per batch
+            }
+            if (st == JPEG_AMD_OK)
+                st = jpeg_amd_jpeg_decode_spectral(h_jpeg[base + i], nbytes[base + i], planes,
+                        reinterpret_cast<uint16_t(*)[64]>(host + quanta_off + (size_t)i * kQSlotElems * 2), nullptr);
+            status[i] = st;
+        });
+        for (int st : status) if (st != JPEG_AMD_OK) result = st;
+        if (result != JPEG_AMD_OK) break;
+        // the device side of chunk k (asynchronous); the host moves on to chunk k + 1 meanwhile
+        size_t stride[JPEG_AMD_MAX_PLANES] = {};
+        for (int c = 0; c < nc; ++c) {
+            stride[c] = plane[c];
+            JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c], host + coef_off[c], plane[c] * 2 * m, hipMemcpyHostToDevice, ctx->stream));
+        }
+        JA_HIP(ctx, hipMemcpyAsync(dev + quanta_off, host + quanta_off, (size_t)m * kQSlotElems * 2, hipMemcpyHostToDevice, ctx->stream));
+        JA_TRY(jpeg_amd_decode_batch(ctx, &L, m, d_coef, stride, reinterpret_cast<const uint16_t *>(dev + quanta_off), kQSlotElems,
+                                     JPEG_AMD_MAX_PLANES, cosited, color, reinterpret_cast<uint8_t *>(dev + px_off), npx));
+        JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->stream));
+        JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->stream));
+        if (k >= 1) JA_TRY(drain(k - 1));
+    }
+    if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); return result; }
+    JA_TRY(drain(nchunks - 1));
+    return JPEG_AMD_OK;
 }
 
 // ---- pixels -> JPEG bytes (the fused device path + host entropy encode) ----------------------

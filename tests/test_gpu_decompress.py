@@ -68,3 +68,26 @@ def test_python_mirror_decompress(ctx, name):
     assert G.sha(rgb) == e["gold"]["rgb_sha256"]
     fused = J.Spectral.decompress(ctx, open(path, "rb").read()).decode(J.RGB).cpu().numpy()
     assert (fused == rgb).all()
+
+
+def test_decompress_batch_matches_single_image_calls(ctx):
+    """jpeg_amd_decompress_batch: several files of one geometry, host threads + one fused launch."""
+    import jpeg_amd as J
+    lib = _lib.lib()
+    names = ["color-sequential-1.jpg", "color-progressive-1.jpg"]          # same 319x480 4:2:0 frame
+    files = [np.fromfile(G.path(G.entry(n)["file"]), np.uint8) for n in names] * 5
+    n = len(files)
+    info = _lib.FrameInfo()
+    w, h = G.entry(names[0])["width"], G.entry(names[0])["height"]
+    out = np.zeros((n, w * h * 3), np.uint8)
+    ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in files])
+    sizes = (C.c_size_t * n)(*[f.size for f in files])
+    st = lib.jpeg_amd_decompress_batch(ctx.handle, ptrs, sizes, n, 3, 0, J.RGB.code, out.ctypes.data, 0, C.byref(info))
+    assert st == 0, st
+    for i in range(n):
+        assert G.sha(out[i]) == G.entry(names[i % 2])["gold"]["rgb_sha256"]
+    # a file of another geometry in the batch is a precondition failure
+    other = np.fromfile(G.path(G.entry("karlie-2019.jpg")["file"]), np.uint8)
+    ptrs2 = (C.c_void_p * 2)(files[0].ctypes.data, other.ctypes.data)
+    sizes2 = (C.c_size_t * 2)(files[0].size, other.size)
+    assert lib.jpeg_amd_decompress_batch(ctx.handle, ptrs2, sizes2, 2, 2, 0, J.RGB.code, out.ctypes.data, 0, None) == _lib.EINVAL

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the file path: JPEG bytes in host memory -> RGB bytes in host memory
+(host Huffman decode on T threads, PCIe both ways, fused GPU decode).  The files are 1080p
+4:2:0 baseline JPEGs written by this library's own encoder from a synthetic frame.
+    python tools/bench_files.py [--n 256] [--threads 1 8 64]"""
+import argparse, ctypes as C, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import jpeg_amd as J
+from jpeg_amd import _lib
+ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=256); ap.add_argument("--threads", type=int, nargs="*", default=[1, 8, 32, 64])
+args = ap.parse_args()
+ctx = J.Context(0); lib = _lib.lib()
+W, H = 1920, 1080
+yy, xx = np.mgrid[0:H, 0:W]
+rng = np.random.default_rng(5)
+layout = J.Layout("ycc8", {1: ((2, 2), 0), 2: ((1, 1), 1), 3: ((1, 1), 1)})
+quanta = {0: J.compression_quanta("luminance", 1.0), 1: J.compression_quanta("chrominance", 1.0)}
+files = []
+for i in range(8):   # 8 distinct frames, cycled
+    base = 128 + 70 * np.sin(xx / (40.0 + 7 * i)) * np.cos(yy / (29.0 + 3 * i))
+    rgb = np.clip(base[..., None] + rng.integers(-12, 13, (H, W, 3)) + np.array([0, 10, -10]), 0, 255).astype(np.uint8).reshape(-1, 3)
+    data = J.Rectangular.pack(ctx, (W, H), layout, rgb, J.RGB).compress(quanta, [[(0, 0, 0)], [(1, 1, 1), (2, 1, 1)]],
+                                                                          metadata=[("jfif", (2, 2, 1, 1))])
+    files.append(np.frombuffer(data, np.uint8).copy())
+n = args.n
+batch = [files[i % 8] for i in range(n)]
+ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in batch]); sizes = (C.c_size_t * n)(*[f.size for f in batch])
+out = np.zeros((n, W * H * 3), np.uint8)
+mb = sum(f.size for f in batch) / 1e6
+print(f"{n} files of {W}x{H}, {mb/n*1e3:.0f} KB each")
+for t in args.threads:
+    for rep in range(2):
+        t0 = time.perf_counter()
+        st = lib.jpeg_amd_decompress_batch(ctx.handle, ptrs, sizes, n, t, 0, J.RGB.code, out.ctypes.data, 0, None)
+        dt = time.perf_counter() - t0
+        assert st == 0, st
+    print(f"  {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s  {mb/dt:8.0f} MB/s of JPEG")
+# host entropy decode alone, one thread
+info = _lib.FrameInfo(); f = batch[0]
+planes = [np.zeros((a[1], a[0], 64), np.int16) for a in layout.units((W, H))]; q = np.zeros((4, 64), np.uint16)
+t0 = time.perf_counter()
+for _ in range(20):
+    lib.jpeg_amd_jpeg_decode_spectral(f.ctypes.data, f.size, _lib.ptr_array([p.ctypes.data for p in planes]), q.ctypes.data, None)
+dt = (time.perf_counter() - t0) / 20
+print(f"host entropy decode alone: {dt*1e3:.2f} ms per file on one thread = {W*H/dt/1e6:.0f} Mpx/s, {f.size/dt/1e6:.0f} MB/s")

@@ -88,3 +88,30 @@ def test_config5_slice_batch_of_1080p(env):
     # cheap whole-batch witness: every image differs from its neighbour (no aliasing of strides)
     sums = batch.to(e["torch"].int64).sum(dim=1).cpu().numpy()
     assert len(set(sums.tolist())) == n
+
+
+@pytest.mark.parametrize("size", [(65535, 24), (24, 65535)], ids=["widest", "tallest"])
+def test_extreme_aspect_ratios_at_the_frame_header_limit(size):
+    """The frame header stores width and height in 16 bits (decode.swift:793-800): the widest
+    and the tallest image a JPEG can describe, 4:2:0, through the fused decode and encode."""
+    import jpeg_amd as J
+    from oracle import oracle as O
+    ctx = J.Context()
+    rng = np.random.default_rng(7)
+    layout = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    units = layout.units(size)
+    planes = []
+    for ux, uy in units:
+        c = rng.integers(-300, 300, (uy, ux, 64)).astype(np.int16)
+        c[..., 6:] //= 16
+        planes.append(c)
+    quanta = [J.compression_quanta("luminance", 1.0), J.compression_quanta("chrominance", 1.0)]
+    spectral = J.Spectral.from_host(ctx, size, layout, planes, quanta, q=[0, 1, 1])
+    got = spectral.decode(J.RGB).cpu().numpy()
+    _, rect = O.decode(planes, [quanta[0], quanta[1], quanta[1]], [(2, 2), (1, 1), (1, 1)], size, threads=8)
+    want = O.unpack_rgb8(rect, 3, threads=8)
+    assert (got == want).all()
+    coef = J.Rectangular.encode(ctx, size, layout, want, {0: quanta[0], 1: quanta[1]}, J.RGB).host_planes()
+    ref = O.encode(want, size, [(2, 2), (1, 1), (1, 1)], [quanta[0], quanta[1], quanta[1]], threads=8)
+    for a, b in zip(coef, ref):
+        assert (a == b).all()

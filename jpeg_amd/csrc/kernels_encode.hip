@@ -18,6 +18,9 @@
 //   - the colour results need no clamp before truncation: Y in [0, 255.0001], Cb/Cr in
 //     [0.5, 255.5], so floor() alone is clamp + truncate;
 //   - Float(sum) / Float(n) truncated, n in {1, 2, 4}, is floor(sum * (1/n)) exactly.
+//
+// Development switches (tools/build_exp.sh, never in the product build): JA_X_ENC_NOSTORE,
+// JA_X_ENC_L2LOAD -- the kernel without its stores / with every load hitting L2.
 #pragma clang fp contract(off)
 
 #include "dct.hpp"

@@ -20,6 +20,11 @@
 // max(i, 0) at the left/top edge reproduces the reference's t = 0 case (decode.swift:4240,
 // 4250) because 0.25*c + 0.75*c == c exactly.  Everything that rounds (dequantise, IDCT,
 // colour matrix) is evaluated op-for-op as in dct.hpp / the reference.
+//
+// Development switches (never defined in the product build; tools/build_exp.sh makes A/B builds,
+// DESIGN.md section 6 quotes the measurements): JA_PHASE_PROFILE (per-phase cycle counters,
+// tools/phase_profile.py), JA_X_NOIDCT / JA_X_NOSTORE (the kernel without its arithmetic / without
+// its stores), JA_X_SKIPK1 / JA_X_SKIPK2 (one launch of the pair only, tools/probe_overlap.py).
 #pragma clang fp contract(off)
 
 #include "dct.hpp"

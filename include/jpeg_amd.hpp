@@ -17,6 +17,8 @@
 #pragma once
 
 #include <cstdint>
+#include <algorithm>
+#include <array>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -287,6 +289,67 @@ class spectral {
         return px.host();
     }
 
+    /// Spectral.decompress(stream:) (decode.swift:3728): a JPEG file's bytes -> coefficient planes
+    /// in HBM; the entropy decoding runs on the host inside the library.  Component c gets quanta
+    /// key c.  `ids` (optional) receives the component identifiers of the frame header.
+    static spectral decompress(const context &c, const std::vector<uint8_t> &file, std::vector<int> *ids = nullptr)
+    {
+        jpeg_amd_frame_info fi{};
+        check(jpeg_amd_jpeg_inspect(file.data(), file.size(), &fi), "jpeg_amd_jpeg_inspect");
+        layout l;
+        l.precision = fi.precision;
+        std::vector<std::vector<int16_t>> coef((size_t)fi.ncomponents);
+        int16_t *ptr[JPEG_AMD_MAX_PLANES] = {};
+        for (int p = 0; p < fi.ncomponents; ++p) {
+            l.planes.push_back({{fi.factor_x[p], fi.factor_y[p]}, p});
+            coef[p].resize((size_t)64 * fi.units_x[p] * fi.units_y[p]);
+            ptr[p] = coef[p].data();
+            if (ids) ids->push_back(fi.id[p]);
+        }
+        uint16_t quanta[JPEG_AMD_MAX_PLANES][64];
+        check(jpeg_amd_jpeg_decode_spectral(file.data(), file.size(), ptr, quanta, nullptr), "jpeg_amd_jpeg_decode_spectral");
+        quanta_map qm;
+        for (int p = 0; p < fi.ncomponents; ++p) qm[p] = std::vector<uint16_t>(quanta[p], quanta[p] + 64);
+        return from_host(c, {fi.width, fi.height}, std::move(l), coef, qm);
+    }
+
+    /// Spectral.compress(stream:) (encode.swift:1918-1972): the file's bytes.  `ids`: component
+    /// identifiers in plane order (ascending); `scans`: the layout's scan progression;
+    /// `process`: 0 baseline, 1 extended, 2 progressive; `metadata`: records written after SOI.
+    std::vector<uint8_t> compress(const std::vector<int> &ids, const std::vector<jpeg_amd_scan> &scans, int process = 0,
+                                  const std::vector<jpeg_amd_metadata> &metadata = {}) const
+    {
+        if ((int)ids.size() != lay.count()) throw error(JPEG_AMD_EINVAL, "one identifier per plane");
+        jpeg_amd_frame_info fi{};
+        fi.width = size.x; fi.height = size.y; fi.precision = lay.precision; fi.ncomponents = lay.count();
+        fi.process = process; fi.scale_x = lay.scale().x; fi.scale_y = lay.scale().y;
+        std::vector<std::vector<int16_t>> host;
+        const int16_t *ptr[JPEG_AMD_MAX_PLANES] = {};
+        std::vector<int32_t> qkey, tkeys;
+        std::vector<uint16_t> tabs;
+        for (int p = 0; p < lay.count(); ++p) {
+            fi.id[p] = ids[p];
+            fi.factor_x[p] = lay.planes[p].factor.x; fi.factor_y[p] = lay.planes[p].factor.y;
+            fi.units_x[p] = units[p].x; fi.units_y[p] = units[p].y;
+            host.push_back(planes[p].host());
+            qkey.push_back(lay.planes[p].qi);
+            if (std::find(tkeys.begin(), tkeys.end(), lay.planes[p].qi) == tkeys.end()) {
+                tkeys.push_back(lay.planes[p].qi);
+                tabs.insert(tabs.end(), tables.begin() + 64 * q[p], tables.begin() + 64 * q[p] + 64);
+            }
+        }
+        for (int p = 0; p < lay.count(); ++p) ptr[p] = host[p].data();
+        size_t n = 0;
+        auto call = [&](uint8_t *out, size_t cap) {
+            return jpeg_amd_jpeg_encode_spectral(&fi, qkey.data(), ptr, tabs.data(), tkeys.data(), (int)tkeys.size(), scans.data(),
+                                                 (int)scans.size(), metadata.data(), (int)metadata.size(), out, cap, &n);
+        };
+        check(call(nullptr, 0), "jpeg_amd_jpeg_encode_spectral");
+        std::vector<uint8_t> out(n);
+        check(call(out.data(), out.size()), "jpeg_amd_jpeg_encode_spectral");
+        return out;
+    }
+
     const context *ctx;
     size2 size;
     layout lay;
@@ -295,6 +358,18 @@ class spectral {
     std::vector<uint16_t> tables;  // [table][64] zigzag
     std::vector<int> q;            // Plane.q
 };
+
+/// JPEG.Header.Scan.sequential((c, dc, ac), ...) over plane indices (jpeg.swift:1648-1670)
+inline jpeg_amd_scan sequential_scan(std::initializer_list<std::array<int, 3>> components)
+{
+    jpeg_amd_scan s{};
+    for (const auto &c : components) {
+        if (s.ncomponents >= JPEG_AMD_MAX_PLANES) throw error(JPEG_AMD_EINVAL, "too many scan components");
+        s.component[s.ncomponents] = c[0]; s.dc[s.ncomponents] = c[1]; s.ac[s.ncomponents] = c[2];
+        ++s.ncomponents;
+    }
+    return s;
+}
 
 inline planar rectangular::decomposed() const
 {

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <iterator>
+#include <string>
 
 #include "jpeg_amd.hpp"
 
@@ -23,9 +25,53 @@ static void dump(const std::string &path, const std::vector<T> &v)
     f.write(reinterpret_cast<const char *>(v.data()), v.size() * sizeof(T));
 }
 
+// host_mirror --file <in.jpg> <out_prefix> [rgb.bin W H]: the file-level calls.
+// Spectral.decompress(path:) -> idct().interleaved().unpack(as: RGB) into <prefix>.rgb, the planes
+// compressed again as a baseline file with the scan structure of examples/encode-basic
+// (<prefix>.jpg), and -- given raw RGB -- Rectangular.pack(...).compress(path:quanta:) of it with
+// the tables of the file (<prefix>.enc.jpg), like examples/encode-basic/main.swift.
+static int file_mode(int argc, char **argv)
+{
+    std::ifstream in(argv[2], std::ios::binary);
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    const std::string prefix = argv[3];
+    try {
+        context ctx(0);
+        std::vector<int> ids;
+        spectral s = spectral::decompress(ctx, file, &ids);
+        dump(prefix + ".rgb", s.idct().interleaved(false).unpack(color::rgb));
+        if (s.lay.count() == 3) {
+            // decompress gives every component its own quanta key; the example's layout shares
+            // key 1 between Cb and Cr (main.swift:36-40), which decides the DQT slots
+            s.lay.planes[2].qi = s.lay.planes[1].qi;
+            const std::vector<jpeg_amd_scan> scans = {sequential_scan({{0, 0, 0}}), sequential_scan({{1, 1, 1}, {2, 1, 1}})};
+            jpeg_amd_metadata jfif{};
+            jfif.kind = 0; jfif.jfif = {2, 2, 1, 1};
+            dump(prefix + ".jpg", s.compress(ids, scans, 0, {jfif}));
+            if (argc == 7) {
+                std::ifstream rin(argv[4], std::ios::binary);
+                std::vector<uint8_t> rgb((std::istreambuf_iterator<char>(rin)), std::istreambuf_iterator<char>());
+                const size2 size{std::atoi(argv[5]), std::atoi(argv[6])};
+                const layout lay = s.lay;                         // keys 0, 1, 1
+                quanta_map quanta;
+                quanta[0] = std::vector<uint16_t>(s.tables.begin(), s.tables.begin() + 64);
+                quanta[1] = std::vector<uint16_t>(s.tables.begin() + 64, s.tables.begin() + 128);
+                const spectral e = rectangular::pack(ctx, size, lay, rgb, color::rgb).decomposed().fdct(quanta);
+                dump(prefix + ".enc.jpg", e.compress(ids, scans, 0, {jfif}));
+            }
+        }
+    } catch (const error &e) {
+        std::cerr << "jpeg_amd error: " << e.what() << "\n";
+        return 1;
+    }
+    std::puts("ok");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    if (argc != 3) { std::cerr << "usage: host_mirror in.bin out_prefix\n"; return 2; }
+    if (argc >= 4 && std::string(argv[1]) == "--file") return file_mode(argc, argv);
+    if (argc != 3) { std::cerr << "usage: host_mirror in.bin out_prefix | --file in.jpg out_prefix [rgb W H]\n"; return 2; }
     std::ifstream in(argv[1], std::ios::binary);
     auto rd = [&]() { int32_t v; in.read(reinterpret_cast<char *>(&v), 4); return v; };
     const size2 size{rd(), rd()};

@@ -59,3 +59,26 @@ def test_cpp_mirror_reproduces_gold(tmp_path, name):
     for p, w in enumerate(want):
         got = np.fromfile(prefix + f".coef{p}", np.int16).reshape(w.shape)
         assert (got == w).all()
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_file_level_calls(tmp_path):
+    """spectral::decompress / spectral::compress of the mirror: a reference-encoded file decodes
+    to the oracle's pixels, compresses back to the SAME bytes, and the example's source picture
+    compresses to the reference's own file (examples/encode-basic)."""
+    import hashlib
+    exe = _build(tmp_path)
+    case = next(c for c in G.encode_cases() if c["mode"] == "4-2-0" and c["level"] == 1.0)
+    src = G.path(case["file"])
+    rgb, (w, h) = G.encode_source()
+    raw = tmp_path / "src.rgb"
+    raw.write_bytes(rgb.tobytes())
+    prefix = str(tmp_path / "f")
+    r = subprocess.run([exe, "--file", src, prefix, str(raw), str(w), str(h)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+    from oracle import jpeg_reader
+    img = jpeg_reader.read_jpeg(src)
+    _, rect = O.decode(img.planes, img.quanta, img.factors, (img.width, img.height))
+    assert (np.fromfile(prefix + ".rgb", np.uint8) == O.unpack_rgb8(rect, 3).reshape(-1)).all()
+    assert open(prefix + ".jpg", "rb").read() == open(src, "rb").read()
+    assert hashlib.sha256(open(prefix + ".enc.jpg", "rb").read()).hexdigest() == case["file_sha256"]

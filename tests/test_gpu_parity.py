@@ -296,3 +296,41 @@ def test_host_buffer_abi(J, ctx):
     assert lib.jpeg_amd_host_planar_fdct(ctx.handle, C.byref(EL), _lib.ptr_array([p.ctypes.data for p in eplanes]),
                                          eq.ctypes.data, 2, _lib.ptr_array([c.ctypes.data for c in ecoef2])) == 0
     assert [G.sha(c) for c in ecoef2] == case["coef_sha256"]
+
+
+# ---- seeded sweep over frame geometry: every edge path of the fused kernels -----------------
+
+def _sweep_cases(n=48):
+    rng = np.random.default_rng(77)
+    cases = []
+    for i in range(n):
+        w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), 16 * rng.integers(1, 40), 256 * rng.integers(1, 3) + rng.integers(-3, 4)]))
+        h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), 16 * rng.integers(1, 12) + rng.integers(-2, 3)]))
+        fac = [(1, 1), (2, 1), (1, 2), (2, 2)][int(rng.integers(4))]
+        cases.append((max(w, 1), max(h, 1), fac, bool(rng.integers(2)), int(rng.integers(3))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _sweep_cases(), ids=lambda c: f"{c[0]}x{c[1]}-{c[2][0]}{c[2][1]}-{'rgb' if c[3] else 'ycc'}-{c[4]}")
+def test_fused_kernels_on_random_geometry(J, ctx, case):
+    """Fused decode and fused encode against the oracle for sizes that hit partial strips,
+    partial tiles, rows that are not 16-byte multiples (byte-wise store tail), single blocks,
+    and grey images (mode 2)."""
+    w, h, fac, rgb, mode = case
+    comps = [((1, 1), 0)] if mode == 2 else [(fac, 0), ((1, 1), 1), ((1, 1), 1)]
+    layout, planes, quanta, q = _random_spectral(J, ctx, (w, h), comps, None, 8, 1000 + w * 7 + h)
+    factors = [c.factor for c in layout.planes]
+    spectral = J.Spectral.from_host(ctx, (w, h), layout, planes, quanta, q=q)
+    color, unpack = (J.RGB, O.unpack_rgb8) if rgb else (J.YCbCr, O.unpack_ycc8)
+    got = spectral.decode(color).cpu().numpy()
+    _, rect = O.decode(planes, [quanta[i] for i in q], factors, (w, h))
+    want = unpack(rect, len(comps))
+    assert (got == want).all(), f"decode: {(got != want).sum()} bytes differ"
+    # encode the decoded picture again
+    qmap = {i: quanta[i] for i in set(q)}
+    coef = J.Rectangular.encode(ctx, (w, h), layout, want, qmap, color).host_planes()
+    pack = O.pack_rgb8 if rgb else O.pack_ycc8
+    planar = O.decompose(pack(want, len(comps)).reshape(h, w, len(comps)), (w, h), factors, layout.scale)
+    enc = [O.fdct_plane(p, quanta[i]) for p, i in zip(planar, q)]
+    for a, b in zip(coef, enc):
+        assert (a == b).all(), "encode differs"

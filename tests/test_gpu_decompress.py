@@ -91,3 +91,32 @@ def test_decompress_batch_matches_single_image_calls(ctx):
     ptrs2 = (C.c_void_p * 2)(files[0].ctypes.data, other.ctypes.data)
     sizes2 = (C.c_size_t * 2)(files[0].size, other.size)
     assert lib.jpeg_amd_decompress_batch(ctx.handle, ptrs2, sizes2, 2, 2, 0, J.RGB.code, out.ctypes.data, 0, None) == _lib.EINVAL
+
+
+def test_two_contexts_on_two_threads():
+    """A jpeg_amd_ctx is single-threaded, different contexts may run concurrently (SURVEY 8b,
+    "Threading"): two host threads, each with its own context and stream, decode different files
+    over and over; every result must be the gold."""
+    import threading
+    import jpeg_amd as J
+    names = ["color-sequential-2.jpg", "grayscale-progressive-1.jpg"]
+    errors = []
+
+    def worker(name):
+        try:
+            c = J.Context(0, own_stream=True)
+            e = G.entry(name)
+            for _ in range(25):
+                got = _decompress(c, G.path(e["file"]), J.RGB)
+                if G.sha(got) != e["gold"]["rgb_sha256"]:
+                    errors.append(name)
+                    return
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+
+    threads = [threading.Thread(target=worker, args=(n,)) for n in names]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

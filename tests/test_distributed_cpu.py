@@ -47,3 +47,40 @@ def test_two_ranks_gloo(tmp_path):
         assert sorted(map(int, r["digests"])) == list(range(r["lo"], r["hi"]))
         merged.update(r["digests"])
     assert merged == want
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("size,factors", [((200, 333), [(2, 2), (1, 1), (1, 1)]), ((96, 64), [(2, 1), (1, 1), (1, 1)]),
+                                           ((50, 90), [(1, 1), (1, 1), (1, 1)])])
+def test_bands_of_one_image_equal_the_whole_decode(world, size, factors):
+    """jpeg_amd.dist.band: every rank decodes its MCU rows + one halo MCU row as an independent
+    sub-image (the oracle stands in for the kernels); stacking the kept rows gives the whole-image
+    decode bit for bit."""
+    import numpy as np
+    from jpeg_amd import dist as jd
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    scale = (max(f[0] for f in factors), max(f[1] for f in factors))
+    units = [O.plane_units(size, f, scale) for f in factors]
+    planes = []
+    for ux, uy in units:
+        c = rng.integers(-200, 200, (uy, ux, 64)).astype(np.int16)
+        c[..., 10:] //= 16
+        planes.append(c)
+    quanta = [rng.integers(1, 30, 64).astype(np.uint16) for _ in factors]
+    _, rect = O.decode(planes, quanta, factors, size)
+    whole = O.unpack_rgb8(rect, 3).reshape(size[1], size[0], 3)
+    rows = []
+    for rank in range(world):
+        plan = jd.band(size, scale, rank, world)
+        if plan is None:
+            continue
+        sub = []
+        for p, (f, (ux, uy)) in zip(planes, zip(factors, units)):
+            u0, u1 = jd.band_units(plan, f[1], uy)
+            sub.append(np.ascontiguousarray(p[u0:u1]))
+        _, r = O.decode(sub, quanta, factors, (size[0], plan["height"]))
+        px = O.unpack_rgb8(r, 3).reshape(plan["height"], size[0], 3)
+        y0, y1 = plan["rows"]
+        rows.append(px[plan["skip"]:plan["skip"] + (y1 - y0)])
+    assert (np.concatenate(rows) == whole).all()

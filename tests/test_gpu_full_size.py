@@ -115,3 +115,31 @@ def test_extreme_aspect_ratios_at_the_frame_header_limit(size):
     ref = O.encode(want, size, [(2, 2), (1, 1), (1, 1)], [quanta[0], quanta[1], quanta[1]], threads=8)
     for a, b in zip(coef, ref):
         assert (a == b).all()
+
+
+def test_one_image_in_bands_across_ranks_is_bit_identical():
+    """jpeg_amd.dist.band on the device path: a 2048 x 1544 4:2:0 image decoded as 3 bands (each
+    with its one-MCU-row halo, zero-copy row slices of the resident planes) equals the whole-image
+    fused decode -- the strong-scaling split of SURVEY.md 8e, ranks simulated one after another."""
+    import torch
+    import jpeg_amd as J
+    from jpeg_amd import dist as jd, synth
+    ctx = J.Context()
+    size = (2048, 1544)
+    layout = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    units = layout.units(size)
+    planes = [p[0] for p in synth.natural_planes_torch(units, 1, ctx.torch_device, 11)]
+    quanta = [J.compression_quanta("luminance", 1.0), J.compression_quanta("chrominance", 1.0)]
+    whole = J.Spectral(ctx, size, layout, [p.view(uy, ux, 64) for p, (ux, uy) in zip(planes, units)], quanta, [0, 1, 1]).decode(J.RGB)
+    whole = whole.view(size[1], size[0], 3)
+    world, rows = 3, []
+    for rank in range(world):
+        plan = jd.band(size, layout.scale, rank, world)
+        sub = []
+        for p, c, (ux, uy) in zip(planes, layout.planes, units):
+            u0, u1 = jd.band_units(plan, c.factor[1], uy)
+            sub.append(p.view(uy, ux, 64)[u0:u1])
+        px = J.Spectral(ctx, (size[0], plan["height"]), layout, sub, quanta, [0, 1, 1]).decode(J.RGB).view(plan["height"], size[0], 3)
+        y0, y1 = plan["rows"]
+        rows.append(px[plan["skip"]:plan["skip"] + (y1 - y0)])
+    assert torch.equal(torch.cat(rows), whole)

@@ -215,6 +215,12 @@ int jpeg_amd_jpeg_inspect(const uint8_t *h_jpeg, size_t nbytes, jpeg_amd_frame_i
  * zigzag (zeroed here first); h_quanta[c] receives the table bound to component c (zigzag). */
 int jpeg_amd_jpeg_decode_spectral(const uint8_t *h_jpeg, size_t nbytes, int16_t *const h_coef[],
                                   uint16_t h_quanta[][64], jpeg_amd_frame_info *info);
+/* The same with the restart intervals of every scan decoded by `nthreads` host threads
+ * (<= 0: all cores): intervals are independent bit streams (DC predictors and EOB runs reset at
+ * RSTn, decode.swift:3210, 3500-3502).  Files without DRI, or with a damaged marker sequence,
+ * take the sequential path. */
+int jpeg_amd_jpeg_decode_spectral_mt(const uint8_t *h_jpeg, size_t nbytes, int16_t *const h_coef[],
+                                     uint16_t h_quanta[][64], jpeg_amd_frame_info *info, int nthreads);
 /* Rectangular.decompress(stream:cosite:) + unpack(as:)  (decode.swift:4367, os.swift:375):
  * JPEG bytes in, H*W colours of 3 bytes out (host memory); 8-bit images of 1 or 3 components. */
 int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes, int cosited,

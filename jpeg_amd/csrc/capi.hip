@@ -754,7 +754,7 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
         coef[c] = planes[c].data();
     }
     uint16_t quanta[JPEG_AMD_MAX_PLANES][64];
-    JA_TRY(jpeg_amd_jpeg_decode_spectral(h_jpeg, nbytes, coef, quanta, nullptr));
+    JA_TRY(jpeg_amd_jpeg_decode_spectral_mt(h_jpeg, nbytes, coef, quanta, nullptr, 0));   // restart intervals in parallel
 
     jpeg_amd_layout L{};
     L.width = fi.width; L.height = fi.height; L.precision = 8; L.nplanes = fi.ncomponents;

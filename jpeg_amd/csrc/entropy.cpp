@@ -13,7 +13,9 @@
 //     progressive DC-first scan) from whatever the DQT slot holds then   :3447-3473, 3486-3496
 //   - coefficients are stored quantised, zigzag order                    :1434, 1466
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/jpeg_amd.h"
@@ -133,6 +135,8 @@ struct Decoder {
     bool qdefined[4] = {false, false, false, false};
     Huffman dc[4], ac[4];
     int restart_interval = 0;
+    int nthreads = 1;            // host threads for restart-interval-parallel scans
+    bool auto_threads = false;   // nthreads chosen by the library: only where a thread pays off
     int nscans = 0;
 
     static int units(int size, int stride) { return size / stride + (size % stride != 0 ? 1 : 0); }
@@ -167,6 +171,22 @@ struct Decoder {
         }
         return JPEG_AMD_OK;
     }
+    // clearing a large plane is worth sharing too (200 MB for an 8192 x 8192 image)
+    void zero_plane(int16_t *p, size_t bytes) const
+    {
+        const size_t piece = (size_t)4 << 20;
+        const int t_n = (int)std::min<size_t>((size_t)nthreads, bytes / piece);
+        if (t_n < 2) { std::memset(p, 0, bytes); return; }
+        std::vector<std::thread> pool;
+        const size_t per = (bytes / t_n + 63) & ~(size_t)63;
+        for (int t = 0; t < t_n; ++t)
+            pool.emplace_back([=] {
+                const size_t lo = std::min(bytes, per * t), hi = t + 1 == t_n ? bytes : std::min(bytes, per * (t + 1));
+                std::memset(reinterpret_cast<char *>(p) + lo, 0, hi - lo);
+            });
+        for (std::thread &th : pool) th.join();
+    }
+
     // Height 0 in the frame header: the real height follows the FIRST scan in a DNL segment
     // (T.81 B.2.5; JPEG.Header.HeightRedefinition, decode.swift:837-860, Context.push(height:)).
     // The planes are sized before that scan is decoded, so the DNL is looked up ahead of time.
@@ -285,16 +305,13 @@ struct Decoder {
         const long total = (long)mcux * mcuy;
         const long ri = restart_interval ? restart_interval : total;
 
-        BitReader br(ecs, end);
+        // One restart interval (or the whole scan): MCUs [mcu0, mcu1) from `br`, predictors and
+        // the EOB run starting from zero (T.81 E.2.4).  Intervals touch disjoint blocks.
+        auto run_interval = [&](BitReader &br, long mcu0, long mcu1) -> int {
         int pred[4] = {0, 0, 0, 0};
         int eobrun = 0;
         int16_t dummy[64];
-        for (long mcu = 0; mcu < total; ++mcu) {
-            if (mcu && mcu % ri == 0) {
-                br.restart();
-                pred[0] = pred[1] = pred[2] = pred[3] = 0;
-                eobrun = 0;
-            }
+        for (long mcu = mcu0; mcu < mcu1; ++mcu) {
             const int my = (int)(mcu / mcux), mx = (int)(mcu - (long)my * mcux);
             for (int si = 0; si < nslots; ++si) {
                 const Slot &sl = slots[si];
@@ -391,6 +408,47 @@ struct Decoder {
             }
         }
         return JPEG_AMD_OK;
+        };   // run_interval
+
+        const long nintervals = (total + ri - 1) / ri;
+        // a thread is worth starting for a few thousand blocks, not less
+        const long useful = std::min<long>(nthreads, std::min<long>(nintervals, auto_threads ? total * nslots / 4096 : nintervals));
+        if (useful > 1) {
+            // Restart-interval-parallel decoding: the intervals of a scan are
+            // independent bit streams separated by RSTn markers.  Only when every marker is
+            // where it should be; a damaged stream takes the sequential path below, which
+            // resynchronises like the reference.
+            std::vector<const uint8_t *> starts{ecs};
+            for (const uint8_t *q = ecs; q + 1 < end;) {
+                q = static_cast<const uint8_t *>(std::memchr(q, 0xff, (size_t)(end - 1 - q)));
+                if (!q) break;
+                if (q[1] >= 0xd0 && q[1] <= 0xd7) starts.push_back(q + 2);
+                q += q[1] == 0xff ? 1 : 2;          // 0xFF fill bytes may precede a marker
+            }
+            if ((long)starts.size() == nintervals) {
+                std::vector<int> status((size_t)nintervals, JPEG_AMD_OK);
+                const int t_n = (int)useful;
+                auto work = [&](int t) {
+                    for (long k = t; k < nintervals; k += t_n) {
+                        BitReader br(starts[(size_t)k], k + 1 < nintervals ? starts[(size_t)k + 1] - 2 : end);
+                        status[(size_t)k] = run_interval(br, k * ri, std::min(total, (k + 1) * ri));
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (int t = 1; t < t_n; ++t) pool.emplace_back(work, t);
+                work(0);
+                for (std::thread &th : pool) th.join();
+                for (int st : status) if (st != JPEG_AMD_OK) return st;
+                return JPEG_AMD_OK;
+            }
+        }
+        BitReader br(ecs, end);
+        for (long k = 0; k < nintervals; ++k) {
+            if (k) br.restart();
+            const int st = run_interval(br, k * ri, std::min(total, (k + 1) * ri));
+            if (st != JPEG_AMD_OK) return st;
+        }
+        return JPEG_AMD_OK;
     }
 
     // Walk the whole file.  coef == nullptr: headers only (fills info, counts scans).
@@ -426,7 +484,7 @@ struct Decoder {
                             for (int c = 0; c < info.ncomponents; ++c) {
                                 if (!coef[c]) return JPEG_AMD_EINVAL;
                                 comps[c].coef = coef[c];
-                                std::memset(coef[c], 0, (size_t)128 * comps[c].ux * comps[c].uy);
+                                zero_plane(coef[c], (size_t)128 * comps[c].ux * comps[c].uy);
                             }
                     }
                     break;
@@ -442,7 +500,9 @@ struct Decoder {
                     // entropy-coded data runs to the next marker that is not RSTn / stuffing
                     size_t e = pos;
                     while (e + 1 < n) {
-                        if (data[e] != 0xff) { ++e; continue; }
+                        const void *ff = std::memchr(data + e, 0xff, n - 1 - e);
+                        if (!ff) { e = n; break; }
+                        e = (size_t)(static_cast<const uint8_t *>(ff) - data);
                         const int m = data[e + 1];
                         if (m == 0x00 || (m >= 0xd0 && m <= 0xd7)) { e += 2; continue; }
                         if (m == 0xff) { ++e; continue; }
@@ -482,8 +542,16 @@ int jpeg_amd_jpeg_inspect(const uint8_t *data, size_t nbytes, jpeg_amd_frame_inf
 int jpeg_amd_jpeg_decode_spectral(const uint8_t *data, size_t nbytes, int16_t *const h_coef[],
                                   uint16_t h_quanta[][64], jpeg_amd_frame_info *info)
 {
+    return jpeg_amd_jpeg_decode_spectral_mt(data, nbytes, h_coef, h_quanta, info, 1);
+}
+
+int jpeg_amd_jpeg_decode_spectral_mt(const uint8_t *data, size_t nbytes, int16_t *const h_coef[],
+                                     uint16_t h_quanta[][64], jpeg_amd_frame_info *info, int nthreads)
+{
     if (!data || !h_coef || !h_quanta) return JPEG_AMD_EINVAL;
     Decoder d{data, nbytes};
+    d.nthreads = nthreads > 0 ? nthreads : (int)std::max(1u, std::thread::hardware_concurrency());
+    d.auto_threads = nthreads <= 0;
     const int st = d.run(h_coef, h_quanta);
     if (st != JPEG_AMD_OK) return st;
     for (const Component &c : d.comps)

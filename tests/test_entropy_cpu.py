@@ -117,3 +117,39 @@ def test_height_defined_by_a_dnl_segment():
         os.unlink(f.name)
     assert (info.width, info.height) == (e["width"], e["height"])
     assert [G.sha(p) for p in planes] == e["coef_sha256"]
+
+
+@pytest.mark.parametrize("name", [n for n in G.decode_names() if "restart" in n])
+@pytest.mark.parametrize("threads", [2, 7, 0])
+def test_restart_interval_parallel_decoding(name, threads):
+    """jpeg_amd_jpeg_decode_spectral_mt: the restart intervals of each scan on several host
+    threads (sequential and progressive files) give the same planes as the sequential decoder."""
+    e = G.entry(name)
+    assert e["restart_interval"] > 0
+    lib = _lib.lib()
+    data = np.fromfile(G.path(e["file"]), np.uint8)
+    info = _lib.FrameInfo()
+    assert lib.jpeg_amd_jpeg_inspect(data.ctypes.data, data.size, C.byref(info)) == 0
+    planes = [np.full((info.units_y[c], info.units_x[c], 64), 55, np.int16) for c in range(info.ncomponents)]
+    quanta = np.zeros((4, 64), np.uint16)
+    st = lib.jpeg_amd_jpeg_decode_spectral_mt(data.ctypes.data, data.size, _lib.ptr_array([p.ctypes.data for p in planes]),
+                                              quanta.ctypes.data, None, threads)
+    assert st == 0
+    assert [G.sha(p) for p in planes] == e["coef_sha256"]
+
+
+def test_parallel_decoder_falls_back_when_a_restart_marker_is_missing():
+    e = G.entry("color-sequential-restart.jpg")
+    data = bytearray(np.fromfile(G.path(e["file"]), np.uint8).tobytes())
+    sos = data.index(b"\xff\xda")
+    i = data.index(b"\xff\xd0", sos)
+    data[i:i + 2] = b"\x12\x34"                      # destroy the first RST0: the interval count no longer matches
+    buf = np.frombuffer(bytes(data), np.uint8).copy()
+    lib = _lib.lib()
+    info = _lib.FrameInfo()
+    assert lib.jpeg_amd_jpeg_inspect(buf.ctypes.data, buf.size, C.byref(info)) in (0, _lib.EINVAL)
+    planes = [np.zeros((info.units_y[c], info.units_x[c], 64), np.int16) for c in range(3)]
+    q = np.zeros((4, 64), np.uint16)
+    a = lib.jpeg_amd_jpeg_decode_spectral_mt(buf.ctypes.data, buf.size, _lib.ptr_array([p.ctypes.data for p in planes]), q.ctypes.data, None, 4)
+    b = lib.jpeg_amd_jpeg_decode_spectral(buf.ctypes.data, buf.size, _lib.ptr_array([p.ctypes.data for p in planes]), q.ctypes.data, None)
+    assert a == b                                    # same verdict as the sequential decoder, no crash

@@ -125,6 +125,13 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: run `python -m jpeg_amd.build` (hipcc, gfx950). "
                 "jpeg_amd has no CPU fallback.")
+        # PyTorch-ROCm ships its own HIP runtime; when both live in one process it has to be the
+        # one loaded FIRST, otherwise the context created later sees no device (ENODEV).  The
+        # host-only entry points (entropy coder) do not need torch at all: a missing torch is fine.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the header and the library diverge

@@ -739,6 +739,7 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
                         jpeg_amd_frame_info *info_out)
 {
     JA_TRY(bind(ctx));
+    if (!h_jpeg) return JPEG_AMD_EINVAL;
     jpeg_amd_frame_info fi;
     JA_TRY(jpeg_amd_jpeg_inspect(h_jpeg, nbytes, &fi));
     if (info_out) *info_out = fi;
@@ -746,25 +747,9 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
     if (fi.precision != 8 || (fi.ncomponents != 1 && fi.ncomponents != 3)) return JPEG_AMD_ENOSUP;
     const size_t need = (size_t)fi.width * fi.height * 3;
     if (!h_pixels || pixel_capacity < need) return JPEG_AMD_EINVAL;
-
-    std::vector<std::vector<int16_t>> planes((size_t)fi.ncomponents);
-    int16_t *coef[JPEG_AMD_MAX_PLANES] = {};
-    for (int c = 0; c < fi.ncomponents; ++c) {
-        planes[c].resize((size_t)64 * fi.units_x[c] * fi.units_y[c]);
-        coef[c] = planes[c].data();
-    }
-    uint16_t quanta[JPEG_AMD_MAX_PLANES][64];
-    JA_TRY(jpeg_amd_jpeg_decode_spectral_mt(h_jpeg, nbytes, coef, quanta, nullptr, 0));   // restart intervals in parallel
-
-    jpeg_amd_layout L{};
-    L.width = fi.width; L.height = fi.height; L.precision = 8; L.nplanes = fi.ncomponents;
-    L.scale_x = fi.scale_x; L.scale_y = fi.scale_y;
-    for (int c = 0; c < fi.ncomponents; ++c) {
-        L.factor_x[c] = fi.factor_x[c]; L.factor_y[c] = fi.factor_y[c];
-        L.units_x[c] = fi.units_x[c];   L.units_y[c] = fi.units_y[c];
-        L.qi[c] = c;
-    }
-    return jpeg_amd_host_decode(ctx, &L, coef, &quanta[0][0], fi.ncomponents, cosited, color, h_pixels);
+    // a batch of one: pinned staging kept in the context, restart intervals and the copy-out on
+    // host threads (their number left to the library)
+    return jpeg_amd_decompress_batch(ctx, &h_jpeg, &nbytes, 1, 0, cosited, color, h_pixels, need, nullptr);
 }
 
 // ---- many JPEG files of one geometry -> pixels: host threads entropy-decode a chunk into
@@ -821,8 +806,9 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
         JA_HIP(ctx, hipMalloc(&ctx->file_device, slot_bytes));
         ctx->file_device_bytes = slot_bytes;
     }
-    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
-    nthreads = std::max(1, std::min(nthreads, chunk));
+    const bool auto_threads = nthreads <= 0;
+    if (auto_threads) nthreads = (int)std::thread::hardware_concurrency();
+    nthreads = std::max(1, nthreads);
 
     char *dev = static_cast<char *>(ctx->file_device);
     const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
@@ -843,7 +829,12 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
         JA_HIP(ctx, hipEventSynchronize(ctx->file_done[slot]));
         const uint8_t *src = static_cast<const uint8_t *>(ctx->file_pinned[slot]) + px_off;
-        parallel(m, [&](int i) { std::memcpy(h_pixels + (size_t)(base + i) * pixel_stride, src + npx * i, npx); });
+        // copy out in pieces of <= 8 MiB so that one huge image is shared by the threads too
+        const size_t piece = (size_t)8 << 20, per_image = (npx + piece - 1) / piece;
+        parallel((int)(per_image * m), [&](int j) {
+            const size_t i = (size_t)j / per_image, lo = ((size_t)j % per_image) * piece, len = std::min(piece, npx - lo);
+            std::memcpy(h_pixels + (size_t)(base + i) * pixel_stride + lo, src + npx * i + lo, len);
+        });
         return JPEG_AMD_OK;
     };
     for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
@@ -864,9 +855,12 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
                     same = f.factor_x[c] == fi.factor_x[c] && f.factor_y[c] == fi.factor_y[c];
                 if (!same) st = JPEG_AMD_EINVAL;             // one geometry per batch
             }
+            // fewer files than threads: the spare threads go to the restart intervals of each file
+            const int inner = std::max(1, nthreads / m);
             if (st == JPEG_AMD_OK)
-                st = jpeg_amd_jpeg_decode_spectral(h_jpeg[base + i], nbytes[base + i], planes,
-                        reinterpret_cast<uint16_t(*)[64]>(host + quanta_off + (size_t)i * kQSlotElems * 2), nullptr);
+                st = jpeg_amd_jpeg_decode_spectral_mt(h_jpeg[base + i], nbytes[base + i], planes,
+                        reinterpret_cast<uint16_t(*)[64]>(host + quanta_off + (size_t)i * kQSlotElems * 2), nullptr,
+                        inner > 1 && auto_threads ? 0 : inner);
             status[i] = st;
         });
         for (int st : status) if (st != JPEG_AMD_OK) result = st;

@@ -120,3 +120,14 @@ def test_two_contexts_on_two_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_library_loaded_before_the_context_still_finds_the_device():
+    """Host-only calls (jpeg_amd.inspect) load libjpeg_amd.so before any context exists; PyTorch
+    brings its own HIP runtime and the two must agree -- in a fresh interpreter."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import jpeg_amd as J; "
+            "i = J.inspect(%r); c = J.Context(0); print('ok', i.width)" % (root, G.path(G.entry("karlie-2019.jpg")["file"])))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok 640" in r.stdout, r.stderr[-400:]

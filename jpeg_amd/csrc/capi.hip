@@ -31,7 +31,9 @@ struct jpeg_amd_ctx {
     void *file_pinned[2] = {nullptr, nullptr};
     void *file_device = nullptr;
     size_t file_pinned_bytes = 0, file_device_bytes = 0;
-    hipEvent_t file_done[2] = {nullptr, nullptr};
+    hipEvent_t file_done[2] = {nullptr, nullptr};     // chunk's pixels are back in pinned memory
+    hipEvent_t file_decoded[2] = {nullptr, nullptr};  // chunk's kernels are done (device -> host copy may start)
+    hipStream_t file_d2h = nullptr;                   // downloads overlap the next chunk's uploads (full-duplex PCIe)
 };
 
 namespace {
@@ -199,7 +201,9 @@ int jpeg_amd_ctx_destroy(jpeg_amd_ctx *ctx)
     for (int i = 0; i < 2; ++i) {
         if (ctx->file_pinned[i]) (void)hipHostFree(ctx->file_pinned[i]);
         if (ctx->file_done[i]) (void)hipEventDestroy(ctx->file_done[i]);
+        if (ctx->file_decoded[i]) (void)hipEventDestroy(ctx->file_decoded[i]);
     }
+    if (ctx->file_d2h) (void)hipStreamDestroy(ctx->file_d2h);
     if (ctx->file_device) (void)hipFree(ctx->file_device);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -797,22 +801,22 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
             ctx->file_pinned_bytes = 0;
             JA_HIP(ctx, hipHostMalloc(&ctx->file_pinned[i], slot_bytes, hipHostMallocDefault));
             if (!ctx->file_done[i]) JA_HIP(ctx, hipEventCreateWithFlags(&ctx->file_done[i], hipEventDisableTiming));
+            if (!ctx->file_decoded[i]) JA_HIP(ctx, hipEventCreateWithFlags(&ctx->file_decoded[i], hipEventDisableTiming));
         }
         ctx->file_pinned_bytes = slot_bytes;
     }
-    if (ctx->file_device_bytes < slot_bytes) {
+    if (!ctx->file_d2h) JA_HIP(ctx, hipStreamCreateWithFlags(&ctx->file_d2h, hipStreamNonBlocking));
+    if (ctx->file_device_bytes < 2 * slot_bytes) {           // two device slots as well
         JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        JA_HIP(ctx, hipStreamSynchronize(ctx->file_d2h));
         if (ctx->file_device) { (void)hipFree(ctx->file_device); ctx->file_device = nullptr; ctx->file_device_bytes = 0; }
-        JA_HIP(ctx, hipMalloc(&ctx->file_device, slot_bytes));
-        ctx->file_device_bytes = slot_bytes;
+        JA_HIP(ctx, hipMalloc(&ctx->file_device, 2 * slot_bytes));
+        ctx->file_device_bytes = 2 * slot_bytes;
     }
     const bool auto_threads = nthreads <= 0;
     if (auto_threads) nthreads = (int)std::thread::hardware_concurrency();
     nthreads = std::max(1, nthreads);
 
-    char *dev = static_cast<char *>(ctx->file_device);
-    const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
-    for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<const int16_t *>(dev + coef_off[c]);
 
     // run `fn(i)` for i in [0, m) on the pool (the calling thread takes a share)
     auto parallel = [&](int m, auto &&fn) {
@@ -865,7 +869,12 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
         });
         for (int st : status) if (st != JPEG_AMD_OK) result = st;
         if (result != JPEG_AMD_OK) break;
-        // the device side of chunk k (asynchronous); the host moves on to chunk k + 1 meanwhile
+        // the device side of chunk k (asynchronous); the host moves on to chunk k + 1 meanwhile.
+        // Device slot `slot` was last read by the download of chunk k - 2, finished before drain(k - 2)
+        // returned.  Upload + kernels on the context's stream, download on the second one.
+        char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
+        const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+        for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<const int16_t *>(dev + coef_off[c]);
         size_t stride[JPEG_AMD_MAX_PLANES] = {};
         for (int c = 0; c < nc; ++c) {
             stride[c] = plane[c];
@@ -874,11 +883,13 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
         JA_HIP(ctx, hipMemcpyAsync(dev + quanta_off, host + quanta_off, (size_t)m * kQSlotElems * 2, hipMemcpyHostToDevice, ctx->stream));
         JA_TRY(jpeg_amd_decode_batch(ctx, &L, m, d_coef, stride, reinterpret_cast<const uint16_t *>(dev + quanta_off), kQSlotElems,
                                      JPEG_AMD_MAX_PLANES, cosited, color, reinterpret_cast<uint8_t *>(dev + px_off), npx));
-        JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->stream));
-        JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->stream));
+        JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
+        JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
+        JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
+        JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->file_d2h));
         if (k >= 1) JA_TRY(drain(k - 1));
     }
-    if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); return result; }
+    if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->file_d2h); return result; }
     JA_TRY(drain(nchunks - 1));
     return JPEG_AMD_OK;
 }

@@ -102,8 +102,9 @@ def test_long_zero_runs_follow_the_reference_rule():
                                                         q2.ctypes.data, None) == 0
         assert (back == blk).all()
         # the DHT of the AC table lists ZRL (0xf0) exactly when 63 - last >= 16
-        i = bytes(out).find(b"\xff\xc4")
-        dht = bytes(out[i + 4:i + 2 + (out[i + 2] << 8 | out[i + 3])])
+        raw = bytes(out)
+        i = raw.find(b"\xff\xc4")
+        dht = raw[i + 4:i + 2 + (raw[i + 2] << 8 | raw[i + 3])]
         ac = dht[dht.index(0x10, 17):]
         assert (0xf0 in ac[17:]) == (63 - last >= 16)
         assert (0x00 in ac[17:]) == ((63 - last) % 16 != 0)
@@ -210,3 +211,87 @@ def _sorted_dht(b):
                 j += 1
             out += b[i:j]; i = j
     return bytes(out)
+
+
+# ---- randomised round trips: writer -> reader over scan scripts the fixtures do not cover ------
+def _frame(w, h, factors, process):
+    info = _lib.FrameInfo()
+    info.width, info.height, info.precision, info.ncomponents, info.process = w, h, 8, len(factors), process
+    sx, sy = max(f[0] for f in factors), max(f[1] for f in factors)
+    for c, (fx, fy) in enumerate(factors):
+        info.id[c], info.factor_x[c], info.factor_y[c] = c + 1, fx, fy
+        info.units_x[c] = -(-w * fx // (8 * sx)); info.units_y[c] = -(-h * fy // (8 * sy))
+    return info
+
+
+def _random_planes(info, rng, density):
+    planes = []
+    for c in range(info.ncomponents):
+        shape = (info.units_y[c], info.units_x[c], 64)
+        mag = rng.integers(-600, 600, shape)
+        mag[..., 1:] = mag[..., 1:] // (1 + np.arange(1, 64) // 3)
+        keep = rng.random(shape) < density
+        keep[..., 0] = True
+        planes.append(np.ascontiguousarray((mag * keep).astype(np.int16)))
+    return planes
+
+
+def _round_trip(info, planes, scans):
+    n = info.ncomponents
+    tables = np.stack([np.arange(1, 65), np.arange(2, 66)]).astype(np.uint16)
+    keys = [0] + [1] * (n - 1)
+    st, out = _encode(info, planes, keys, tables, [0, 1][:max(1, min(2, n))] if n > 1 else [0], scans=scans, metadata=None)
+    assert st == 0, st
+    back = [np.full_like(p, 7) for p in planes]
+    q = np.zeros((4, 64), np.uint16)
+    info2 = _lib.FrameInfo()
+    assert _lib.lib().jpeg_amd_jpeg_decode_spectral(out.ctypes.data, out.size, _lib.ptr_array([p.ctypes.data for p in back]),
+                                                    q.ctypes.data, C.byref(info2)) == 0
+    assert info2.nscans == len(scans)
+    for a, b in zip(planes, back):
+        assert (a == b).all(), f"{(a != b).sum()} coefficients differ"
+    return out
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_progressive_scripts_round_trip(seed):
+    rng = np.random.default_rng(seed)
+    factors = [[(2, 2), (1, 1), (1, 1)], [(1, 1), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)]][seed % 3]
+    info = _frame(int(rng.integers(9, 200)), int(rng.integers(9, 200)), factors, 2)
+    planes = _random_planes(info, rng, density=[0.02, 0.3, 0.9][seed % 3])
+    al = int(rng.integers(0, 3))                     # successive approximation depth
+    scans = [Scan.progressive_dc((0, 0), (1, 1), (2, 1), bits=al)]
+    scans += [Scan.progressive_dc_refine(0, 1, 2, bit=b) for b in range(al - 1, -1, -1)]
+    for c in range(3):
+        cuts = sorted(set([1, 64] + [int(x) for x in rng.integers(2, 64, int(rng.integers(0, 3)))]))
+        for lo, hi in zip(cuts, cuts[1:]):
+            scans.append(Scan.progressive_ac((c, int(rng.integers(0, 4))), (lo, hi), bits=al))
+    for b in range(al - 1, -1, -1):
+        for c in rng.permutation(3):
+            scans.append(Scan.progressive_ac_refine((int(c), int(rng.integers(0, 4))), (1, 64), bit=b))
+    _round_trip(info, planes, scans)
+
+
+@pytest.mark.parametrize("process,scans", [
+    (0, [[(0, 0, 0), (1, 1, 1), (2, 1, 1)]]),
+    (0, [[(0, 0, 0)], [(1, 1, 1)], [(2, 0, 1)]]),
+    (1, [[(0, 3, 2), (1, 1, 0)], [(2, 2, 3)]]),
+])
+def test_random_sequential_scripts_round_trip(process, scans):
+    rng = np.random.default_rng(11)
+    info = _frame(123, 77, [(2, 2), (1, 1), (1, 1)], process)
+    _round_trip(info, _random_planes(info, rng, 0.2), scans)
+
+
+def test_eob_runs_longer_than_4096_blocks_are_split():
+    """encode.swift:1092-1099: an EOB run grows while it is below 4096 blocks, then a new one
+    starts -- 90 x 90 blocks with no AC coefficient at all make two and a bit runs."""
+    info = _frame(720, 720, [(1, 1)], 2)
+    planes = [np.zeros((90, 90, 64), np.int16)]
+    planes[0][..., 0] = np.random.default_rng(3).integers(-100, 100, (90, 90))
+    planes[0][60, 0, 5] = 9                                # 5 400 empty blocks come first: 4 096 + 1 304
+    out = _round_trip(info, planes, [Scan.progressive_dc((0, 0), bits=0), Scan.progressive_ac((0, 0), (1, 64), bits=0)])
+    raw = bytes(out)
+    i = raw.rfind(b"\xff\xc4")
+    dht = raw[i + 4:i + 2 + (raw[i + 2] << 8 | raw[i + 3])]
+    assert 0xc0 in dht[17:]                                # EOB12: a run of 4096 was coded

@@ -294,6 +294,17 @@ int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8
                       size_t capacity,
                       size_t *nbytes);
 
+/* The same for n_images pictures of ONE geometry, tables and scan progression: image i at
+ * h_pixels + i * pixel_stride (0 = W*H*3); file i is written to h_out + i * out_stride and is
+ * nbytes[i] long (EINVAL with nbytes[i] > out_stride: that buffer was too small).  One fused
+ * encode launch per chunk, the entropy coding on `nthreads` host threads (<= 0: all cores). */
+int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels,
+                            size_t pixel_stride, int n_images, jpeg_amd_color color,
+                            const int32_t *quanta_key, const uint16_t *h_quanta,
+                            const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans,
+                            int nscans, const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
+                            uint8_t *h_out, size_t out_stride, size_t nbytes[]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -933,4 +933,83 @@ int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8
                                          metadata, nmetadata, h_out, capacity, nbytes);
 }
 
+// ---- many pictures of one geometry -> JPEG files: one fused encode launch per chunk, the host
+//      threads entropy-code the planes of a chunk as soon as they are back ------------------------
+int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels,
+                            size_t pixel_stride, int n_images, jpeg_amd_color color,
+                            const int32_t *quanta_key, const uint16_t *h_quanta, const int32_t *h_quanta_keys,
+                            int ntables, const jpeg_amd_scan *scans, int nscans,
+                            const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
+                            uint8_t *h_out, size_t out_stride, size_t nbytes[])
+{
+    JA_TRY(bind(ctx));
+    if (!frame || !h_pixels || !quanta_key || !h_quanta || !h_quanta_keys || !scans || !h_out || !nbytes || n_images < 0)
+        return JPEG_AMD_EINVAL;
+    if (n_images == 0) return JPEG_AMD_OK;
+    const int nc = frame->ncomponents;
+    if (frame->precision != 8 || (nc != 1 && nc != 3)) return JPEG_AMD_ENOSUP;
+    if (frame->width < 1 || frame->height < 1 || ntables < 1 || ntables > JPEG_AMD_MAX_PLANES) return JPEG_AMD_EINVAL;
+    const size_t npx = (size_t)frame->width * frame->height * 3;
+    if (pixel_stride == 0) pixel_stride = npx;
+    if (pixel_stride < npx) return JPEG_AMD_EINVAL;
+
+    jpeg_amd_layout L{};
+    L.width = frame->width; L.height = frame->height; L.precision = 8; L.nplanes = nc;
+    L.scale_x = L.scale_y = 1;
+    for (int c = 0; c < nc; ++c) {
+        if (frame->factor_x[c] < 1 || frame->factor_y[c] < 1) return JPEG_AMD_EINVAL;
+        L.factor_x[c] = frame->factor_x[c]; L.factor_y[c] = frame->factor_y[c];
+        L.scale_x = std::max(L.scale_x, L.factor_x[c]); L.scale_y = std::max(L.scale_y, L.factor_y[c]);
+        L.qi[c] = -1;
+        for (int t = 0; t < ntables; ++t) if (h_quanta_keys[t] == quanta_key[c]) L.qi[c] = t;
+        if (L.qi[c] < 0) return JPEG_AMD_EINVAL;
+    }
+    JA_TRY(jpeg_amd_layout_units(&L));
+    frame->scale_x = L.scale_x; frame->scale_y = L.scale_y;
+    size_t plane[JPEG_AMD_MAX_PLANES] = {}, stride[JPEG_AMD_MAX_PLANES] = {};
+    for (int c = 0; c < nc; ++c) {
+        frame->units_x[c] = L.units_x[c]; frame->units_y[c] = L.units_y[c];
+        plane[c] = stride[c] = (size_t)64 * L.units_x[c] * L.units_y[c];
+    }
+    const int chunk = std::min(n_images, 32);
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    nthreads = std::max(1, std::min(nthreads, chunk));
+
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
+    DeviceBag bag(ctx);
+    uint8_t *d_px = nullptr;
+    int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+    JA_TRY(bag.alloc(npx * chunk, (void **)&d_px));
+    for (int c = 0; c < nc; ++c) JA_TRY(bag.alloc(plane[c] * 2 * chunk, (void **)&d_coef[c]));
+    std::vector<std::vector<int16_t>> h_coef((size_t)nc);
+    for (int c = 0; c < nc; ++c) h_coef[c].resize(plane[c] * chunk);
+
+    for (int base = 0; base < n_images; base += chunk) {
+        const int m = std::min(chunk, n_images - base);
+        for (int i = 0; i < m; ++i)
+            JA_HIP(ctx, hipMemcpyAsync(d_px + npx * i, h_pixels + (size_t)(base + i) * pixel_stride, npx, hipMemcpyHostToDevice, ctx->stream));
+        JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, d_px, npx, color, d_q, 0, ntables, d_coef, stride));
+        for (int c = 0; c < nc; ++c)
+            JA_HIP(ctx, hipMemcpyAsync(h_coef[c].data(), d_coef[c], plane[c] * 2 * m, hipMemcpyDeviceToHost, ctx->stream));
+        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int> status((size_t)m, JPEG_AMD_OK);
+        auto work = [&](int t) {
+            for (int i = t; i < m; i += nthreads) {
+                const int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
+                for (int c = 0; c < nc; ++c) planes[c] = h_coef[c].data() + plane[c] * i;
+                status[i] = jpeg_amd_jpeg_encode_spectral(frame, quanta_key, planes, h_quanta, h_quanta_keys, ntables, scans, nscans,
+                                                          metadata, nmetadata, h_out + (size_t)(base + i) * out_stride, out_stride,
+                                                          &nbytes[base + i]);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : pool) th.join();
+        for (int st : status) if (st != JPEG_AMD_OK) return st;   // EINVAL with nbytes[i] > out_stride: buffer too small
+    }
+    return JPEG_AMD_OK;
+}
+
 }  // extern "C"

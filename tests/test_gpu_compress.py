@@ -98,3 +98,33 @@ def test_progressive_compress_round_trip(ctx, tmp_path):
     for a, b in zip(spectral.host_planes(), back.host_planes()):
         assert (a == b).all()
     assert all((np.asarray(x) == np.asarray(y)).all() for x, y in zip(back.quanta, [quanta[0], quanta[1], quanta[1]]))
+
+
+def test_compress_batch_writes_the_references_file_for_every_image(ctx):
+    """jpeg_amd_compress_batch: 5 copies of the example picture in one call (host threads do the
+    entropy coding) -- every file is the reference's, and a buffer that is too small is reported."""
+    import jpeg_amd as J
+    case = next(c for c in G.encode_cases() if c["mode"] == "4-2-0" and c["level"] == 0.5)
+    rgb, (w, h) = G.encode_source()
+    n = 5
+    px = np.ascontiguousarray(np.tile(rgb.reshape(1, -1), (n, 1)))
+    info = _lib.FrameInfo()
+    info.width, info.height, info.precision, info.ncomponents, info.process = w, h, 8, 3, 0
+    for c, (fx, fy) in enumerate(case["factors"]):
+        info.id[c], info.factor_x[c], info.factor_y[c] = c + 1, fx, fy
+    tables = _quanta(case["level"])
+    qkey, tk = (C.c_int32 * 3)(0, 1, 1), (C.c_int32 * 2)(0, 1)
+    sarr = _scan_array(SCANS)
+    marr, nmeta, _keep = _metadata_array(JFIF)
+    cap = 1 << 18
+    out = np.zeros((n, cap), np.uint8)
+    sizes = (C.c_size_t * n)()
+    st = _lib.lib().jpeg_amd_compress_batch(ctx.handle, C.byref(info), px.ctypes.data, 0, n, J.RGB.code, qkey, tables.ctypes.data,
+                                            tk, 2, sarr, 2, marr, nmeta, 3, out.ctypes.data, cap, sizes)
+    assert st == 0, st
+    for i in range(n):
+        assert sizes[i] == case["file_nbytes"]
+        assert hashlib.sha256(out[i, :sizes[i]].tobytes()).hexdigest() == case["file_sha256"]
+    st = _lib.lib().jpeg_amd_compress_batch(ctx.handle, C.byref(info), px.ctypes.data, 0, n, J.RGB.code, qkey, tables.ctypes.data,
+                                            tk, 2, sarr, 2, marr, nmeta, 3, out.ctypes.data, 1000, sizes)
+    assert st == _lib.EINVAL and sizes[0] == case["file_nbytes"]

@@ -44,3 +44,25 @@ for _ in range(20):
     lib.jpeg_amd_jpeg_decode_spectral(f.ctypes.data, f.size, _lib.ptr_array([p.ctypes.data for p in planes]), q.ctypes.data, None)
 dt = (time.perf_counter() - t0) / 20
 print(f"host entropy decode alone: {dt*1e3:.2f} ms per file on one thread = {W*H/dt/1e6:.0f} Mpx/s, {f.size/dt/1e6:.0f} MB/s")
+
+# the other direction: RGB bytes in host memory -> baseline JPEG bytes in host memory
+from jpeg_amd.api import _scan_array, _metadata_array
+n = min(args.n, 256)
+px = np.ascontiguousarray(np.tile(rgb.reshape(1, -1), (n, 1)))
+info = _lib.FrameInfo()
+info.width, info.height, info.precision, info.ncomponents, info.process = W, H, 8, 3, 0
+for c, (fx, fy) in enumerate([(2, 2), (1, 1), (1, 1)]):
+    info.id[c], info.factor_x[c], info.factor_y[c] = c + 1, fx, fy
+tables = np.stack([quanta[0], quanta[1]]).astype(np.uint16)
+qkey, tk = (C.c_int32 * 3)(0, 1, 1), (C.c_int32 * 2)(0, 1)
+sarr = _scan_array([[(0, 0, 0)], [(1, 1, 1), (2, 1, 1)]]); marr, nmeta, _k = _metadata_array([("jfif", (2, 2, 1, 1))])
+cap = 1 << 20
+jout = np.zeros((n, cap), np.uint8); jsizes = (C.c_size_t * n)()
+for t in args.threads:
+    for rep in range(2):
+        t0 = time.perf_counter()
+        st = lib.jpeg_amd_compress_batch(ctx.handle, C.byref(info), px.ctypes.data, 0, n, J.RGB.code, qkey, tables.ctypes.data, tk, 2,
+                                         sarr, 2, marr, nmeta, t, jout.ctypes.data, cap, jsizes)
+        dt = time.perf_counter() - t0
+        assert st == 0, st
+    print(f"  compress {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s")

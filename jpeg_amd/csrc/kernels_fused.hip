@@ -3,7 +3,8 @@
 // Replaces idct() -> interleaved(cosite: false) -> unpack(as:) (decode.swift:4154, 4182,
 // 4294) for ycc8 images whose luma has the full sampling factor and whose chroma planes are
 // subsampled 1x or 2x per axis (4:4:4, 4:2:2, 4:4:0, 4:2:0), and for y8 images, without
-// materialising Planar / Rectangular in HBM.  Two launches:
+// materialising Planar / Rectangular in HBM.  Two launches (one for y8 and for 4:4:4, where
+// every work-item transforms the Cb and Cr blocks under its luma block itself):
 //
 //   k_chroma_idct   Cb and Cr: dequantise + IDCT, clamp, store as uint8 planes (a scratch of
 //                   0.5 B/px for 4:2:0 -- small enough to stay in L2 / Infinity Cache).
@@ -99,8 +100,11 @@ __global__ __launch_bounds__(kThreads) void k_chroma_idct(ChromaArgs a)
 struct LumaArgs {
     const int16_t *coef;
     size_t coef_stride;
-    const uint8_t *cb, *cr;  // uint8 planes [ph_c][pw_c] (unused for grey)
+    const uint8_t *cb, *cr;  // uint8 planes [ph_c][pw_c] (unused for grey and for 4:4:4)
     size_t c_stride;
+    const int16_t *ccoef[2]; // 4:4:4: the chroma coefficient planes themselves (same geometry as luma)
+    size_t ccoef_stride[2];
+    int cqi[2];
     const uint16_t *quanta;
     size_t quanta_stride;
     int qi;
@@ -201,12 +205,17 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     constexpr int HY = SY == 2 ? 1 : 0;
     constexpr int PITCH = (CW + 2 * HX) / 4;             // dwords per LDS row
     constexpr int ROWS = CR + 2 * HY;
-    constexpr int PLANE = CHROMA ? ROWS * PITCH : 1;
+    // 4:4:4: no k_chroma_idct launch and no chroma round trip through HBM -- every work-item
+    // transforms the Cb and Cr blocks that lie under its luma block itself (same geometry), parks
+    // their samples as bytes in LDS ([dword][lane], like k_encode_fused) and then does the luma block
+    constexpr bool INTHREAD = CHROMA && SX == 1 && SY == 1;
+    constexpr int PLANE = (CHROMA && !INTHREAD) ? ROWS * PITCH : 1;
     constexpr int SEG_DW = TBX * 6;                      // one 32-block row segment: 768 B
+    constexpr int NTAB = INTHREAD ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][2 * SEG_DW]; // one pixel row x 2 block rows
-    __shared__ uint32_t scw[NW][2 * PLANE];              // chroma samples under the strip (+ halo)
-    __shared__ float sqw[NW][64];                        // modulated table
+    __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
+    __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
 
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // strip math stays scalar
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     uint32_t *sc = scw[wave];
     const uint32_t sc_lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sc);
-    float *sq = sqw[wave];
+    float *sq = sqw[wave][0];
 
     // strip s -> image, strip row (2 block rows), strip column (32 blocks)
     auto locate = [&](int s, int &img, int &syi, int &sxi) {
@@ -230,10 +239,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
 
     // LDS-DMA of the 64 blocks of strip s: instruction i moves 64 x 16 B; slot
     // u = 64 i + lane holds chunk (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3.
-    auto dma_strip = [&](int s, int lane) {
+    auto dma_strip = [&](int s, int lane, int which = 0) {   // which: 0 luma, 1 Cb, 2 Cr (4:4:4 only)
         int img, syi, sxi;
         locate(s, img, syi, sxi);
         const int16_t *base = a.coef + img * a.coef_stride;
+        if constexpr (INTHREAD) {
+            if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
+        }
         if (sxi * TBX + TBX <= a.ux && 2 * syi + 2 <= a.uy) {
             // interior strip (wave-uniform test): the block index is scalar, only the lane's
             // place inside an 8-block group (and its swizzled chunk) is per lane
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     const int nwaves = gridDim.x * NW;
     int s = blockIdx.x * NW + wave;
     if (s >= a.total_tiles) return;
-    dma_strip(s, lane0);
+    dma_strip(s, lane0, INTHREAD ? 1 : 0);
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
 #ifdef JA_PHASE_PROFILE
@@ -283,6 +295,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         if (img != img_of_table) {
             const int qk = lane & 7, qh = lane >> 3;
             sq[lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi + zigzag_of(qk, qh)]);
+            if constexpr (INTHREAD) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    sqw[wave][1 + pl][lane] = modulate_entry(qk, qh, 0.125f,
+                        a.quanta[img * a.quanta_stride + 64 * a.cqi[pl] + zigzag_of(qk, qh)]);
+            }
             img_of_table = img;
         }
 
@@ -295,13 +313,39 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         JA_PHASE(0)
         uint32_t w[32];
-        {
+        auto read_block = [&]() {
             const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
             const int sw = (lane >> 1) & 7;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const uint4 v = cw[i ^ sw];
                 w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+        };
+        read_block();
+        if constexpr (INTHREAD) {
+            // Cb, then Cr: while one plane is transformed the next one's coefficients are on their
+            // way into the (single) LDS buffer -- the block has to be in registers before the DMA
+            // may overwrite it, hence the lgkmcnt wait
+#pragma unroll 1
+            for (int pl = 0; pl < 2; ++pl) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma_strip(s, lane, pl == 0 ? 2 : 0);
+                float g[64];
+                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+#pragma unroll
+                for (int y = 0; y < 8; ++y)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)   // clamp [0, 255] + truncate == saturating convert of floor(v)
+                            v = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 * d + i]), i, v);
+                        sc[(pl * 16 + 2 * y + d) * 64 + lane] = v;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                read_block();
             }
         }
 
@@ -311,7 +355,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         //      the replication a clamped COLUMN needs is patched in LDS on edge strips only. ----
         const int cx0 = sxi * CW, cy0 = syi * CR;
         const int pwd = a.pw_c >> 2;
-        if constexpr (CHROMA) {
+        if constexpr (CHROMA && !INTHREAD) {
             const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + lane, 0), pwd - 1);
             if (lane < PITCH) {
 #pragma unroll
@@ -347,7 +391,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         JA_PHASE(2)
 
         // ---- the chroma rows have landed (they are the only VM operations in flight) ----
-        if constexpr (CHROMA) {
+        if constexpr (CHROMA && !INTHREAD) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int first_bad = pwd - (cx0 - HX) / 4;          // first column past the plane
             if ((HX > 0 && sxi == 0) || first_bad < PITCH) {     // wave-uniform: edge strips only
@@ -361,7 +405,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         }
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
-        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane);
+        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, INTHREAD ? 1 : 0);
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(3)
@@ -378,7 +422,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                                     ubyte<2>(d1), ubyte<3>(d1), ubyte<0>(d2)};
                 lerp_row_2x(p, o);
             } else {
-                const uint32_t d0 = row[2 * lbx], d1 = row[2 * lbx + 1];
+                uint32_t d0, d1;
+                if constexpr (INTHREAD) {   // the block's own samples, parked above
+                    d0 = sc[(pl * 16 + 2 * j) * 64 + lane]; d1 = sc[(pl * 16 + 2 * j + 1) * 64 + lane];
+                } else {
+                    d0 = row[2 * lbx]; d1 = row[2 * lbx + 1];
+                }
                 o[0] = ubyte<0>(d0); o[1] = ubyte<1>(d0); o[2] = ubyte<2>(d0); o[3] = ubyte<3>(d0);
                 o[4] = ubyte<0>(d1); o[5] = ubyte<1>(d1); o[6] = ubyte<2>(d1); o[7] = ubyte<3>(d1);
             }
@@ -578,7 +627,7 @@ bool fused_decode_supported(const jpeg_amd_layout &L, bool cosited)
 
 size_t fused_decode_scratch_bytes(const jpeg_amd_layout &L, int n_images)
 {
-    if (L.nplanes == 1) return 0;
+    if (L.nplanes == 1 || (L.scale_x == 1 && L.scale_y == 1)) return 0;   // grey, 4:4:4: no intermediate
     const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
     return 2 * ((plane * n_images + 255) & ~(size_t)255);
 }
@@ -588,8 +637,16 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
                                uint8_t *d_pixels, size_t pixel_stride)
 {
     const bool chroma = L.nplanes == 3;
+    // 4:4:4: k_luma_fused transforms all three planes itself (no intermediate, no first launch)
+    const bool inthread = chroma && L.scale_x == 1 && L.scale_y == 1;
     LumaArgs la{};
-    if (chroma) {
+    if (inthread) {
+        for (int i = 0; i < 2; ++i) {
+            la.ccoef[i] = static_cast<const int16_t *>(coef.ptr[1 + i]);
+            la.ccoef_stride[i] = coef.stride[1 + i];
+            la.cqi[i] = L.qi[1 + i];
+        }
+    } else if (chroma) {
         const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
         const size_t half = (plane * n_images + 255) & ~(size_t)255;
         ChromaArgs ca{};

@@ -70,6 +70,16 @@ struct BitReader {
 
     inline void refill()
     {
+        // fast path: four bytes at once when none of them is 0xFF (no stuffing, no marker)
+        while (nbits <= 32 && !hit_marker && p + 4 <= end) {
+            uint32_t x;
+            std::memcpy(&x, p, 4);
+            const uint32_t inv = ~x;
+            if ((inv - 0x01010101u) & ~inv & 0x80808080u) break;          // some byte of x is 0xFF
+            acc |= (uint64_t)__builtin_bswap32(x) << (32 - nbits);
+            nbits += 32;
+            p += 4;
+        }
         while (nbits <= 56) {
             uint32_t byte = 0xff;
             if (!hit_marker && p < end) {
@@ -322,8 +332,10 @@ struct Decoder {
                 const int ci = (int)(c - comps.data());
                 if (!inside) std::memset(dummy, 0, sizeof dummy);
                 if (!progressive) {
-                    // sequential: T.81 F.2.2
+                    // sequential: T.81 F.2.2.  The block is cleared here, while it is in cache,
+                    // instead of with the whole plane up front (a quarter of the decode time).
                     if (!dc[sl.td].defined || !ac[sl.ta].defined) return JPEG_AMD_EINVAL;
+                    if (inside) std::memset(blk, 0, 128);
                     const int t = br.decode(dc[sl.td]);
                     if (t < 0 || t > 16) return JPEG_AMD_EINVAL;
                     pred[ci] += extend((int)br.get(t), t);
@@ -484,7 +496,8 @@ struct Decoder {
                             for (int c = 0; c < info.ncomponents; ++c) {
                                 if (!coef[c]) return JPEG_AMD_EINVAL;
                                 comps[c].coef = coef[c];
-                                zero_plane(coef[c], (size_t)128 * comps[c].ux * comps[c].uy);
+                                // progressive scans only add to a block; sequential ones clear it themselves
+                                if (info.process == 2) zero_plane(coef[c], (size_t)128 * comps[c].ux * comps[c].uy);
                             }
                     }
                     break;

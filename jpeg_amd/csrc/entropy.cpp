@@ -30,6 +30,9 @@ struct Huffman {
     int32_t valptr[17];
     int32_t mincode[17];
     uint8_t symbols[256];
+    // AC shortcut: when code + magnitude bits of a coefficient fit in the 9-bit window, one lookup
+    // yields the value: (value << 8) | (run << 4) | total bits; 0 = take the general path
+    int16_t fast_ac[512];
     bool defined = false;
 
     bool build(const uint8_t counts[16], const uint8_t *syms, int nsyms)
@@ -53,6 +56,16 @@ struct Huffman {
             code <<= 1;
         }
         maxcode[17] = 0x7fffffff;
+        for (int i = 0; i < 512; ++i) {
+            fast_ac[i] = 0;
+            const uint16_t f = fast[i];
+            if (!f) continue;
+            const int len = f >> 8, rs = f & 0xff, run = rs >> 4, size = rs & 15;
+            if (size == 0 || len + size > 9) continue;
+            int v = (i >> (9 - len - size)) & ((1 << size) - 1);      // the magnitude bits that follow the code
+            if (v < (1 << (size - 1))) v += 1 - (1 << size);          // T.81 F.2.2.1 extension
+            if (v >= -128 && v <= 127) fast_ac[i] = (int16_t)(v * 256 + run * 16 + len + size);
+        }
         defined = true;
         return true;
     }
@@ -342,6 +355,15 @@ struct Decoder {
                     blk[0] = (int16_t)pred[ci];
                     const Huffman &h = ac[sl.ta];
                     for (int k = 1; k < 64;) {
+                        if (br.nbits < 16) br.refill();
+                        const int fa = h.fast_ac[br.peek(9)];
+                        if (fa) {                                   // run, size and value in one lookup
+                            k += (fa >> 4) & 15;
+                            br.skip(fa & 15);
+                            if (k < 64) blk[k] = (int16_t)(fa >> 8);
+                            ++k;
+                            continue;
+                        }
                         const int rs = br.decode(h);
                         if (rs < 0) return JPEG_AMD_EINVAL;
                         const int r = rs >> 4, s = rs & 15;

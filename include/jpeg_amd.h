@@ -221,6 +221,12 @@ int jpeg_amd_jpeg_decode_spectral(const uint8_t *h_jpeg, size_t nbytes, int16_t 
  * take the sequential path. */
 int jpeg_amd_jpeg_decode_spectral_mt(const uint8_t *h_jpeg, size_t nbytes, int16_t *const h_coef[],
                                      uint16_t h_quanta[][64], jpeg_amd_frame_info *info, int nthreads);
+/* The image as it stands after the first `max_scans` scans (0 = all): what JPEG.Context hands out
+ * between scans (decode.swift:3554-3961, examples/decode-online) -- progressive previews.
+ * Components no scan has reached yet are all zero and get a table of ones. */
+int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *h_jpeg, size_t nbytes, int16_t *const h_coef[],
+                                          uint16_t h_quanta[][64], jpeg_amd_frame_info *info,
+                                          int nthreads, int max_scans);
 /* Rectangular.decompress(stream:cosite:) + unpack(as:)  (decode.swift:4367, os.swift:375):
  * JPEG bytes in, H*W colours of 3 bytes out (host memory); 8-bit images of 1 or 3 components. */
 int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes, int cosited,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "jpeg_amd_jpeg_inspect": (C.c_int, [_p, C.c_size_t, _p]),
     "jpeg_amd_jpeg_decode_spectral": (C.c_int, [_p, C.c_size_t, _pp, _p, _p]),
     "jpeg_amd_jpeg_decode_spectral_mt": (C.c_int, [_p, C.c_size_t, _pp, _p, _p, C.c_int]),
+    "jpeg_amd_jpeg_decode_spectral_partial": (C.c_int, [_p, C.c_size_t, _pp, _p, _p, C.c_int, C.c_int]),
     "jpeg_amd_decompress": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_decompress_batch": (C.c_int, [_p, _pp, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_jpeg_encode_spectral": (C.c_int, [_p, _p, _pp, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),

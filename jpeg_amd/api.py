@@ -272,12 +272,12 @@ class Spectral:
         return data
 
     @classmethod
-    def decompress(cls, ctx: Context, source) -> "Spectral":
+    def decompress(cls, ctx: Context, source, scans: int = 0) -> "Spectral":
         """Spectral.decompress(stream:) / decompress(path:) -- decode.swift:3728, os.swift:309.
         source: a path or the file's bytes.  The entropy-coded segments are decoded on the host
         by the library (csrc/entropy.cpp); the coefficient planes land in HBM."""
         data = _file_bytes(source)
-        info, planes, quanta = _decode_spectral(data)
+        info, planes, quanta = _decode_spectral(data, scans)   # scans > 0: the image after that many scans
         n = info.ncomponents
         if info.precision == 8 and n == 1:
             fmt = "y8"
@@ -372,13 +372,13 @@ def inspect(source) -> _lib.FrameInfo:
     return info
 
 
-def _decode_spectral(data: np.ndarray):
+def _decode_spectral(data: np.ndarray, scans: int = 0):
     info = inspect(data)
     planes = [np.empty((info.units_y[c], info.units_x[c], 64), np.int16) for c in range(info.ncomponents)]
     quanta = np.zeros((MAX_PLANES, 64), np.uint16)
-    _lib.check(_lib.lib().jpeg_amd_jpeg_decode_spectral(
-        data.ctypes.data, data.size, _lib.ptr_array([p.ctypes.data for p in planes]), quanta.ctypes.data, None),
-        "jpeg_amd_jpeg_decode_spectral")
+    _lib.check(_lib.lib().jpeg_amd_jpeg_decode_spectral_partial(
+        data.ctypes.data, data.size, _lib.ptr_array([p.ctypes.data for p in planes]), quanta.ctypes.data, None, 0, scans),
+        "jpeg_amd_jpeg_decode_spectral_partial")
     return info, planes, quanta
 
 

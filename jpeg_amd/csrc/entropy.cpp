@@ -160,6 +160,7 @@ struct Decoder {
     int restart_interval = 0;
     int nthreads = 1;            // host threads for restart-interval-parallel scans
     bool auto_threads = false;   // nthreads chosen by the library: only where a thread pays off
+    int max_scans = 0x7fffffff;  // stop after this many scans (progressive previews, JPEG.Context-style)
     int nscans = 0;
 
     static int units(int size, int stride) { return size / stride + (size % stride != 0 ? 1 : 0); }
@@ -519,7 +520,8 @@ struct Decoder {
                                 if (!coef[c]) return JPEG_AMD_EINVAL;
                                 comps[c].coef = coef[c];
                                 // progressive scans only add to a block; sequential ones clear it themselves
-                                if (info.process == 2) zero_plane(coef[c], (size_t)128 * comps[c].ux * comps[c].uy);
+                                if (info.process == 2 || max_scans != 0x7fffffff)
+                                    zero_plane(coef[c], (size_t)128 * comps[c].ux * comps[c].uy);
                             }
                     }
                     break;
@@ -547,6 +549,7 @@ struct Decoder {
                     st = decode_scan(seg, len, data + pos, data + e, quanta_out);
                     ++nscans;
                     pos = e;
+                    if (nscans >= max_scans) pos = n;   // the caller wants the image as it stands now
                     break;
                 }
                 default: break;                                           // APPn, COM, ...: skipped; DNL: see parse_sof
@@ -583,14 +586,27 @@ int jpeg_amd_jpeg_decode_spectral(const uint8_t *data, size_t nbytes, int16_t *c
 int jpeg_amd_jpeg_decode_spectral_mt(const uint8_t *data, size_t nbytes, int16_t *const h_coef[],
                                      uint16_t h_quanta[][64], jpeg_amd_frame_info *info, int nthreads)
 {
-    if (!data || !h_coef || !h_quanta) return JPEG_AMD_EINVAL;
+    return jpeg_amd_jpeg_decode_spectral_partial(data, nbytes, h_coef, h_quanta, info, nthreads, 0);
+}
+
+int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *data, size_t nbytes, int16_t *const h_coef[],
+                                          uint16_t h_quanta[][64], jpeg_amd_frame_info *info, int nthreads,
+                                          int max_scans)
+{
+    if (!data || !h_coef || !h_quanta || max_scans < 0) return JPEG_AMD_EINVAL;
     Decoder d{data, nbytes};
     d.nthreads = nthreads > 0 ? nthreads : (int)std::max(1u, std::thread::hardware_concurrency());
     d.auto_threads = nthreads <= 0;
+    if (max_scans > 0) {
+        d.max_scans = max_scans;
+        // a component no scan has reached yet is all zeros: any table dequantises it to mid-grey
+        for (int c = 0; c < JPEG_AMD_MAX_PLANES; ++c)
+            for (int z = 0; z < 64; ++z) h_quanta[c][z] = 1;
+    }
     const int st = d.run(h_coef, h_quanta);
     if (st != JPEG_AMD_OK) return st;
     for (const Component &c : d.comps)
-        if (!c.bound) return JPEG_AMD_EINVAL;   // a component no scan ever touched
+        if (!c.bound && max_scans == 0) return JPEG_AMD_EINVAL;   // a component no scan ever touched
     if (info) *info = d.info;
     return JPEG_AMD_OK;
 }

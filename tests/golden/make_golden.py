@@ -160,6 +160,21 @@ def main():
                         "file_nbytes": os.path.getsize(os.path.join(REF, origin))})
     manifest["encode"]["written_by_reference"] = written
 
+    # ---- examples/decode-online: the picture after every scan of a progressive file, as
+    #      JPEG.Context hands it out between scans (pins for partial / online decoding) ----
+    onl = os.path.join(REF, "examples/decode-online")
+    name = "karlie-oscars-2017.jpg"
+    copy(os.path.join(onl, name), os.path.join(HERE, "decode", name))
+    img = R.read_jpeg(os.path.join(onl, name))
+    snaps = []
+    k = 0
+    while os.path.exists(os.path.join(onl, f"{name}-{k}.rgb")):
+        snaps.append({"after_scans": k + 1, "rgb_sha256": sha_file(os.path.join(onl, f"{name}-{k}.rgb")),
+                      "rgb_nbytes": os.path.getsize(os.path.join(onl, f"{name}-{k}.rgb"))})
+        k += 1
+    manifest["online"] = {"file": "decode/" + name, "origin": "examples/decode-online/" + name,
+                          "width": img.width, "height": img.height, "snapshots": snaps}
+
     # ---- attribution ----------------------------------------------------------------------
     with open(os.path.join(HERE, "ATTRIBUTION.md"), "w") as f:
         f.write("# Image fixtures: attribution\n\n"

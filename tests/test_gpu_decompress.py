@@ -131,3 +131,24 @@ def test_library_loaded_before_the_context_still_finds_the_device():
             "i = J.inspect(%r); c = J.Context(0); print('ok', i.width)" % (root, G.path(G.entry("karlie-2019.jpg")["file"])))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok 640" in r.stdout, r.stderr[-400:]
+
+
+def test_twelve_bit_four_component_file_through_the_staged_path(ctx):
+    """examples/custom-color/output.jpg (written by the reference: 12-bit, 4 components, 16-bit
+    quantisation tables, progressive): host entropy decode -> Spectral.idct() -> interleaved()
+    on the device against the oracle (the reference keeps no gold for custom formats)."""
+    import jpeg_amd as J
+    from oracle import oracle as O
+    path = G.path("encode/custom-color-output.jpg")
+    spectral = J.Spectral.decompress(ctx, path)
+    info = J.inspect(path)
+    assert (info.precision, info.ncomponents, info.process) == (12, 4, 2)
+    planes = spectral.host_planes()
+    factors = [c.factor for c in spectral.layout.planes]
+    planar = spectral.idct()
+    want = [O.idct_plane(p, q, 12) for p, q in zip(planes, spectral.quanta)]
+    for got, w in zip(planar.host_planes(), want):
+        assert (got == w).all()
+    rect = planar.interleaved(cosite=False).host_values()
+    assert (rect == O.interleave(want, factors, spectral.layout.scale, spectral.size)).all()
+    assert rect.max() > 255          # really more than 8 bits

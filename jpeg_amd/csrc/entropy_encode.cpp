@@ -189,32 +189,61 @@ struct Sink {   // either counts symbols or writes bits
     std::vector<uint8_t> *out = nullptr;
     uint64_t acc = 0;
     int nacc = 0;
+    uint8_t buf[4096];      // bytes on their way to *out (one vector append per 4 KiB, not per byte)
+    int nbuf = 0;
 
-    void bits(unsigned v, int n)
+    void spill()
+    {
+        out->insert(out->end(), buf, buf + nbuf);
+        nbuf = 0;
+    }
+    void bits(unsigned v, int n)          // n <= 32
     {
         if (n == 0) return;
-        acc = (acc << n) | (v & ((1u << n) - 1u));
+        acc = (acc << n) | ((uint64_t)v & ((1ull << n) - 1ull));
         nacc += n;
+        if (nbuf > (int)sizeof buf - 16) spill();
         while (nacc >= 8) {
             const uint8_t b = (uint8_t)(acc >> (nacc - 8));
-            out->push_back(b);
-            if (b == 0xff) out->push_back(0x00);
+            buf[nbuf++] = b;
+            if (b == 0xff) buf[nbuf++] = 0x00;
             nacc -= 8;
         }
     }
     void finish()
     {
         if (nacc > 0) bits((1u << (8 - nacc)) - 1u, 8 - nacc);   // pad with 1-bits
+        spill();
     }
+    // Sequential scans walk the coefficients ONCE: the statistics pass also records every symbol
+    // as a 32-bit token -- symbol, table (selector + DC/AC), number of magnitude bits, the bits --
+    // and the coding pass only replays the tokens against the finished tables.
+    std::vector<uint32_t> *tokens = nullptr;
+    int dc_sel = 0, ac_sel = 0;
     void dc_symbol(int sym, unsigned tail, int n)
     {
-        if (out) { bits(dc->code[sym], dc->length[sym]); bits(tail, n); }
-        else ++dc_freq[sym];
+        if (out) bits((unsigned)dc->code[sym] << n | tail, dc->length[sym] + n);   // code and magnitude bits together
+        else {
+            ++dc_freq[sym];
+            if (tokens) tokens->push_back((uint32_t)sym | (uint32_t)n << 8 | (uint32_t)dc_sel << 13 | tail << 16);
+        }
     }
     void ac_symbol(int sym, unsigned tail, int n)
     {
-        if (out) { bits(ac->code[sym], ac->length[sym]); bits(tail, n); }
-        else ++ac_freq[sym];
+        if (out) bits((unsigned)ac->code[sym] << n | tail, ac->length[sym] + n);
+        else {
+            ++ac_freq[sym];
+            if (tokens) tokens->push_back((uint32_t)sym | (uint32_t)n << 8 | (uint32_t)(4 + ac_sel) << 13 | tail << 16);
+        }
+    }
+    void replay(const std::vector<uint32_t> &toks, const Codebook *dcb, const Codebook *acb)
+    {
+        for (const uint32_t t : toks) {
+            const int sym = t & 0xff, n = (t >> 8) & 31, table = (t >> 13) & 7;
+            const Codebook &cb = table < 4 ? dcb[table] : acb[table - 4];
+            bits((unsigned)cb.code[sym] << n | (t >> 16), cb.length[sym] + n);
+        }
+        finish();
     }
 };
 
@@ -580,12 +609,15 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
             long dc_freq[4][256], ac_freq[4][256];
             std::memset(dc_freq, 0, sizeof dc_freq);
             std::memset(ac_freq, 0, sizeof ac_freq);
+            std::vector<uint32_t> tokens;
             auto walk = [&](bool emit, std::vector<uint8_t> *ecs, const Codebook *dcb, const Codebook *acb) {
                 Sink s;
                 s.out = emit ? ecs : nullptr;
+                if (!emit) s.tokens = &tokens;
                 int16_t pred[4] = {0, 0, 0, 0};
                 auto select = [&](int j) {
                     s.dc_freq = dc_freq[sc.dc[j]]; s.ac_freq = ac_freq[sc.ac[j]];
+                    s.dc_sel = sc.dc[j]; s.ac_sel = sc.ac[j];
                     if (emit) { s.dc = dcb + sc.dc[j]; s.ac = acb + sc.ac[j]; }
                 };
                 if (ns == 1) {
@@ -633,7 +665,7 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
             }
             sos.push_back(0); sos.push_back(63); sos.push_back(0);
             segment(out, 0xda, sos);
-            walk(true, &out, dcb, acb);
+            { Sink s; s.out = &out; s.replay(tokens, dcb, acb); }
         }
     }
     out.push_back(0xff); out.push_back(0xd9);

@@ -227,6 +227,19 @@ int jpeg_amd_jpeg_decode_spectral_mt(const uint8_t *h_jpeg, size_t nbytes, int16
 int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *h_jpeg, size_t nbytes, int16_t *const h_coef[],
                                           uint16_t h_quanta[][64], jpeg_amd_frame_info *info,
                                           int nthreads, int max_scans);
+/* A decoder fed by a GROWING byte stream -- JPEG.Context driven by a Bytestream.Source that runs
+ * dry (decode.swift:3554-3961; examples/decode-online): push whatever bytes have arrived; every
+ * segment and every scan that is complete by then is consumed, incomplete ones wait for the next
+ * push.  *scans_done counts the scans decoded so far, *finished is set at EOI.  The decoder owns
+ * the planes; jpeg_amd_stream_snapshot copies them (and the table of every component, ones for a
+ * component no scan has reached yet) into caller buffers sized from jpeg_amd_stream_info. */
+typedef struct jpeg_amd_stream jpeg_amd_stream;
+jpeg_amd_stream *jpeg_amd_stream_create(void);
+void jpeg_amd_stream_destroy(jpeg_amd_stream *stream);
+int jpeg_amd_stream_push(jpeg_amd_stream *stream, const uint8_t *h_bytes, size_t nbytes, int *scans_done,
+                         int *finished);
+int jpeg_amd_stream_info(const jpeg_amd_stream *stream, jpeg_amd_frame_info *info);
+int jpeg_amd_stream_snapshot(const jpeg_amd_stream *stream, int16_t *const h_coef[], uint16_t h_quanta[][64]);
 /* Rectangular.decompress(stream:cosite:) + unpack(as:)  (decode.swift:4367, os.swift:375):
  * JPEG bytes in, H*W colours of 3 bytes out (host memory); 8-bit images of 1 or 3 components. */
 int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes, int cosited,

@@ -80,6 +80,11 @@ SIGNATURES = {
     "jpeg_amd_jpeg_decode_spectral": (C.c_int, [_p, C.c_size_t, _pp, _p, _p]),
     "jpeg_amd_jpeg_decode_spectral_mt": (C.c_int, [_p, C.c_size_t, _pp, _p, _p, C.c_int]),
     "jpeg_amd_jpeg_decode_spectral_partial": (C.c_int, [_p, C.c_size_t, _pp, _p, _p, C.c_int, C.c_int]),
+    "jpeg_amd_stream_create": (C.c_void_p, []),
+    "jpeg_amd_stream_destroy": (None, [_p]),
+    "jpeg_amd_stream_push": (C.c_int, [_p, _p, C.c_size_t, _p, _p]),
+    "jpeg_amd_stream_info": (C.c_int, [_p, _p]),
+    "jpeg_amd_stream_snapshot": (C.c_int, [_p, _pp, _p]),
     "jpeg_amd_decompress": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_decompress_batch": (C.c_int, [_p, _pp, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_jpeg_encode_spectral": (C.c_int, [_p, _p, _pp, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -487,22 +488,35 @@ struct Decoder {
     }
 
     // Walk the whole file.  coef == nullptr: headers only (fills info, counts scans).
+    // Resumable: `pos`, `have_frame` and all tables live in the object.  With `streaming` set the
+    // walk stops (status OK, nothing consumed) in front of the first segment or entropy-coded
+    // segment that is not complete yet -- JPEG.Context fed by a growing byte stream
+    // (decode.swift:3554-3961, examples/decode-online); `finished` is set at EOI.
+    size_t pos = 0;
+    bool have_frame = false, streaming = false, finished = false;
+    std::vector<std::vector<int16_t>> own_planes;       // streaming: the decoder owns the planes
+    uint16_t own_quanta[JPEG_AMD_MAX_PLANES][64];
+
     int run(int16_t *const coef[], uint16_t (*quanta_out)[64])
     {
-        if (n < 4 || data[0] != 0xff || data[1] != 0xd8) return JPEG_AMD_EINVAL;
-        size_t pos = 2;
-        bool have_frame = false;
-        while (pos + 1 < n) {
+        if (pos == 0) {
+            if (n < 4) return streaming ? JPEG_AMD_OK : JPEG_AMD_EINVAL;
+            if (data[0] != 0xff || data[1] != 0xd8) return JPEG_AMD_EINVAL;
+            pos = 2;
+        }
+        while (pos + 1 < n && !finished) {
+            const size_t segment_start = pos;
             if (data[pos] != 0xff) return JPEG_AMD_EINVAL;
             while (pos + 1 < n && data[pos + 1] == 0xff) ++pos;
-            if (pos + 1 >= n) break;
+            if (pos + 1 >= n) { if (streaming) pos = segment_start; break; }
             const int marker = data[pos + 1];
             pos += 2;
-            if (marker == 0xd9) break;                                   // EOI
+            if (marker == 0xd9) { finished = true; break; }              // EOI
             if (marker == 0x01 || (marker >= 0xd0 && marker <= 0xd7)) continue;
-            if (pos + 2 > n) return JPEG_AMD_EINVAL;
+            if (pos + 2 > n) { if (streaming) { pos = segment_start; break; } return JPEG_AMD_EINVAL; }
             const size_t seglen = ((size_t)data[pos] << 8) | data[pos + 1];
-            if (seglen < 2 || pos + seglen > n) return JPEG_AMD_EINVAL;
+            if (seglen < 2) return JPEG_AMD_EINVAL;
+            if (pos + seglen > n) { if (streaming) { pos = segment_start; break; } return JPEG_AMD_EINVAL; }
             const uint8_t *seg = data + pos + 2;
             const size_t len = seglen - 2;
             pos += seglen;
@@ -512,8 +526,20 @@ struct Decoder {
                 case 0xc4: st = parse_dht(seg, len); break;
                 case 0xc0: case 0xc1: case 0xc2:
                     if (have_frame) return JPEG_AMD_ENOSUP;
+                    if (streaming && len >= 3 && seg[1] == 0 && seg[2] == 0 && height_from_dnl((size_t)(seg + len - data)) == 0) {
+                        pos = segment_start;                                // height comes with a DNL not here yet
+                        goto out_of_data;
+                    }
                     st = parse_sof(marker, seg, len);
-                    if (st == JPEG_AMD_OK) {
+                    if (st == JPEG_AMD_OK && streaming) {
+                        have_frame = true;
+                        own_planes.assign((size_t)info.ncomponents, {});
+                        for (int c = 0; c < info.ncomponents; ++c) {
+                            own_planes[c].assign((size_t)64 * comps[c].ux * comps[c].uy, 0);
+                            comps[c].coef = own_planes[c].data();
+                            for (int z = 0; z < 64; ++z) own_quanta[c][z] = 1;
+                        }
+                    } else if (st == JPEG_AMD_OK) {
                         have_frame = true;
                         if (coef)
                             for (int c = 0; c < info.ncomponents; ++c) {
@@ -545,8 +571,11 @@ struct Decoder {
                         if (m == 0xff) { ++e; continue; }
                         break;
                     }
-                    if (e + 1 >= n) e = n;
-                    st = decode_scan(seg, len, data + pos, data + e, quanta_out);
+                    if (e + 1 >= n) {
+                        if (streaming) { pos = segment_start; goto out_of_data; }   // the scan's end is not here yet
+                        e = n;
+                    }
+                    st = decode_scan(seg, len, data + pos, data + e, streaming ? own_quanta : quanta_out);
                     ++nscans;
                     pos = e;
                     if (nscans >= max_scans) pos = n;   // the caller wants the image as it stands now
@@ -556,7 +585,8 @@ struct Decoder {
             }
             if (st != JPEG_AMD_OK) return st;
         }
-        if (!have_frame) return JPEG_AMD_EINVAL;
+    out_of_data:
+        if (!have_frame) return streaming ? JPEG_AMD_OK : JPEG_AMD_EINVAL;
         info.nscans = nscans;
         info.restart_interval = restart_interval;
         return JPEG_AMD_OK;
@@ -608,6 +638,53 @@ int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *data, size_t nbytes, in
     for (const Component &c : d.comps)
         if (!c.bound && max_scans == 0) return JPEG_AMD_EINVAL;   // a component no scan ever touched
     if (info) *info = d.info;
+    return JPEG_AMD_OK;
+}
+
+// ---- a decoder fed by a growing byte stream (JPEG.Context, examples/decode-online) ------------
+struct jpeg_amd_stream {
+    std::vector<uint8_t> bytes;
+    Decoder dec{nullptr, 0};
+};
+
+jpeg_amd_stream *jpeg_amd_stream_create(void)
+{
+    jpeg_amd_stream *s = new (std::nothrow) jpeg_amd_stream;
+    if (s) s->dec.streaming = true;
+    return s;
+}
+
+void jpeg_amd_stream_destroy(jpeg_amd_stream *s) { delete s; }
+
+int jpeg_amd_stream_push(jpeg_amd_stream *s, const uint8_t *h_bytes, size_t nbytes, int *scans_done, int *finished)
+{
+    if (!s || (nbytes && !h_bytes)) return JPEG_AMD_EINVAL;
+    s->bytes.insert(s->bytes.end(), h_bytes, h_bytes + nbytes);
+    s->dec.data = s->bytes.data();               // the buffer may have moved: the decoder keeps offsets only
+    s->dec.n = s->bytes.size();
+    const int st = s->dec.run(nullptr, nullptr);
+    if (scans_done) *scans_done = s->dec.nscans;
+    if (finished) *finished = s->dec.finished ? 1 : 0;
+    return st;
+}
+
+int jpeg_amd_stream_info(const jpeg_amd_stream *s, jpeg_amd_frame_info *info)
+{
+    if (!s || !info) return JPEG_AMD_EINVAL;
+    if (!s->dec.have_frame) return JPEG_AMD_EINVAL;   // no frame header yet
+    *info = s->dec.info;
+    info->nscans = s->dec.nscans;
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_stream_snapshot(const jpeg_amd_stream *s, int16_t *const h_coef[], uint16_t h_quanta[][64])
+{
+    if (!s || !h_coef || !h_quanta || !s->dec.have_frame) return JPEG_AMD_EINVAL;
+    for (int c = 0; c < s->dec.info.ncomponents; ++c) {
+        if (!h_coef[c]) return JPEG_AMD_EINVAL;
+        std::memcpy(h_coef[c], s->dec.own_planes[(size_t)c].data(), s->dec.own_planes[(size_t)c].size() * 2);
+        std::memcpy(h_quanta[c], s->dec.own_quanta[c], 128);
+    }
     return JPEG_AMD_OK;
 }
 

@@ -5,6 +5,7 @@
 // status is fine, a sanitizer report is not.  Built and run by tests/test_entropy_sanitize.py.
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -93,6 +94,19 @@ int main(int argc, char **argv)
         if (st != JPEG_AMD_OK) { std::printf("%s: decode status %d\n", argv[a], st); ++failures; continue; }
         Decoded dm;
         if (decode(file, dm, 4) != JPEG_AMD_OK || dm.planes != d.planes) { std::printf("%s: threaded decode differs\n", argv[a]); ++failures; }
+        {   // the same file through the growing-stream decoder, 777 bytes at a time
+            jpeg_amd_stream *st2 = jpeg_amd_stream_create();
+            int done = 0, fin = 0, bad = 0;
+            for (size_t lo = 0; lo < file.size() && !bad; lo += 777)
+                bad = jpeg_amd_stream_push(st2, file.data() + lo, std::min<size_t>(777, file.size() - lo), &done, &fin) != JPEG_AMD_OK;
+            Decoded ds; ds.fi = d.fi; ds.planes = d.planes;
+            int16_t *ptr[JPEG_AMD_MAX_PLANES] = {};
+            for (int c = 0; c < d.fi.ncomponents; ++c) { std::fill(ds.planes[c].begin(), ds.planes[c].end(), (int16_t)3); ptr[c] = ds.planes[c].data(); }
+            if (bad || !fin || jpeg_amd_stream_snapshot(st2, ptr, ds.quanta) != JPEG_AMD_OK || ds.planes != d.planes) {
+                std::printf("%s: stream decode differs\n", argv[a]); ++failures;
+            }
+            jpeg_amd_stream_destroy(st2);
+        }
         for (int progressive = 0; progressive < 2; ++progressive) {
             if (progressive == 0 && d.fi.ncomponents > 2 && d.fi.precision == 8) {
                 // baseline: only two table slots -- components 1.. share the lifetime rules; still must not crash
@@ -118,6 +132,13 @@ int main(int argc, char **argv)
             }
             Decoded junk;
             (void)decode(bad, junk, it & 1 ? 3 : 1);
+            if (it % 8 == 0) {   // corrupted bytes through the stream decoder as well
+                jpeg_amd_stream *st3 = jpeg_amd_stream_create();
+                int done = 0, fin = 0;
+                for (size_t lo = 0; lo < bad.size(); lo += 1500)
+                    if (jpeg_amd_stream_push(st3, bad.data() + lo, std::min<size_t>(1500, bad.size() - lo), &done, &fin) != JPEG_AMD_OK) break;
+                jpeg_amd_stream_destroy(st3);
+            }
         }
     }
     std::printf("%s\n", failures ? "FAILED" : "ok");

@@ -159,6 +159,11 @@ def main():
         written.append({"file": "encode/" + fn, "origin": origin, "file_sha256": sha_file(os.path.join(REF, origin)),
                         "file_nbytes": os.path.getsize(os.path.join(REF, origin))})
     manifest["encode"]["written_by_reference"] = written
+    # examples/in-memory also dumps the decoded picture; the re-compressed file above holds the
+    # same coefficients as the original, so it pins the decode of a progressive 4:4:4 file
+    manifest["in_memory"] = {"file": "encode/karlie-2011.jpg.jpg", "origin": "examples/in-memory/karlie-2011.jpg.rgb",
+                             "rgb_sha256": sha_file(os.path.join(REF, "examples/in-memory/karlie-2011.jpg.rgb")),
+                             "rgb_nbytes": os.path.getsize(os.path.join(REF, "examples/in-memory/karlie-2011.jpg.rgb"))}
 
     # ---- examples/decode-online: the picture after every scan of a progressive file, as
     #      JPEG.Context hands it out between scans (pins for partial / online decoding) ----

@@ -101,3 +101,35 @@ def test_stream_in_tiny_pieces_equals_the_one_shot_decoder(name, piece):
         assert [quanta[c].tolist() for c in range(info.ncomponents)] == e["quanta_zigzag"]
     finally:
         lib.jpeg_amd_stream_destroy(s)
+
+
+def _in_memory():
+    return G.manifest()["in_memory"]
+
+
+def test_in_memory_example_gold_on_the_cpu_path():
+    """examples/in-memory: decompress -> unpack of a progressive 4:4:4 file, dumped as .rgb."""
+    from oracle import oracle as O
+    m = _in_memory()
+    lib = _lib.lib()
+    data = np.fromfile(G.path(m["file"]), np.uint8)
+    info = _lib.FrameInfo()
+    assert lib.jpeg_amd_jpeg_inspect(data.ctypes.data, data.size, C.byref(info)) == 0
+    planes = [np.zeros((info.units_y[c], info.units_x[c], 64), np.int16) for c in range(3)]
+    quanta = np.zeros((4, 64), np.uint16)
+    assert lib.jpeg_amd_jpeg_decode_spectral(data.ctypes.data, data.size, _lib.ptr_array([p.ctypes.data for p in planes]),
+                                             quanta.ctypes.data, None) == 0
+    factors = [(info.factor_x[c], info.factor_y[c]) for c in range(3)]
+    _, rect = O.decode(planes, [quanta[c] for c in range(3)], factors, (info.width, info.height))
+    assert hashlib.sha256(O.unpack_rgb8(rect, 3).tobytes()).hexdigest() == m["rgb_sha256"]
+
+
+@pytest.mark.gpu
+def test_in_memory_example_gold_on_the_device():
+    import jpeg_amd as J
+    m = _in_memory()
+    ctx = J.default_context()
+    rgb = J.Rectangular.decompress(ctx, G.path(m["file"])).unpack(J.RGB).cpu().numpy()
+    assert rgb.size == m["rgb_nbytes"] and hashlib.sha256(rgb.tobytes()).hexdigest() == m["rgb_sha256"]
+    fused = J.Spectral.decompress(ctx, G.path(m["file"])).decode(J.RGB).cpu().numpy()
+    assert (fused == rgb).all()

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Soak: N random frame geometries / layouts / colour targets through the fused decode and encode
 kernels against the oracle (a longer run of tests/test_gpu_parity.py::test_fused_kernels_on_random_geometry).
-    python tools/soak_geometry.py <seed> <cases>"""
+    python tests/soak_geometry.py <seed> <cases>   (not collected by pytest; it uses the oracle, so it lives under tests/)"""
 import sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 import jpeg_amd as J
 from oracle import oracle as O

@@ -294,6 +294,8 @@ typedef struct jpeg_amd_metadata {            /* JPEG.Metadata record, written a
  * quanta_key[c]: quantisation-table key of component c (JPEG.Table.Quantization.Key);
  * h_quanta / h_quanta_keys: ntables tables of 64 zigzag values and their keys.
  * process 2 (progressive) takes progressive scans, 0 / 1 sequential ones.
+ * frame->restart_interval > 0 (an extension: the reference's writer never emits DRI) cuts every
+ * scan into restart intervals of that many MCUs, which the decoder then takes on several threads.
  * h_out == NULL only computes *nbytes. */
 int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_t *quanta_key,
                                   const int16_t *const h_coef[], const uint16_t *h_quanta,

@@ -183,6 +183,8 @@ inline void compact(int16_t x, int &binade, unsigned &tail)
     tail = ((unsigned)(uint16_t)x - sign) & ((1u << binade) - 1u);
 }
 
+constexpr uint32_t kRestartToken = 0xffffffffu;   // table field 7 does not occur otherwise
+
 struct Sink {   // either counts symbols or writes bits
     long *dc_freq = nullptr, *ac_freq = nullptr;
     const Codebook *dc = nullptr, *ac = nullptr;
@@ -215,6 +217,15 @@ struct Sink {   // either counts symbols or writes bits
         if (nacc > 0) bits((1u << (8 - nacc)) - 1u, 8 - nacc);   // pad with 1-bits
         spill();
     }
+    int rst = 0;
+    void restart_marker()                                        // end of a restart interval: pad, RSTm
+    {
+        if (nacc > 0) bits((1u << (8 - nacc)) - 1u, 8 - nacc);
+        if (nbuf > (int)sizeof buf - 16) spill();
+        buf[nbuf++] = 0xff;
+        buf[nbuf++] = (uint8_t)(0xd0 + rst);
+        rst = (rst + 1) & 7;
+    }
     // Sequential scans walk the coefficients ONCE: the statistics pass also records every symbol
     // as a 32-bit token -- symbol, table (selector + DC/AC), number of magnitude bits, the bits --
     // and the coding pass only replays the tokens against the finished tables.
@@ -239,6 +250,7 @@ struct Sink {   // either counts symbols or writes bits
     void replay(const std::vector<uint32_t> &toks, const Codebook *dcb, const Codebook *acb)
     {
         for (const uint32_t t : toks) {
+            if (t == kRestartToken) { restart_marker(); continue; }
             const int sym = t & 0xff, n = (t >> 8) & 31, table = (t >> 13) & 7;
             const Codebook &cb = table < 4 ? dcb[table] : acb[table - 4];
             bits((unsigned)cb.code[sym] << n | (t >> 16), cb.length[sym] + n);
@@ -316,30 +328,37 @@ void scan_header(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const int32
 }
 
 int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const std::vector<Plane> &planes,
-                     const int32_t *ids, int mcux, int mcuy)
+                     const int32_t *ids, int mcux, int mcuy, int ri)
 {
     const int ns = sc.ncomponents, a = sc.bit;
-    // the blocks of the scan in coding order: (plane, x, y); slot j of the scan for table choice
-    auto for_each_block = [&](auto &&fn) {
+    // the blocks of the scan in coding order: (plane, x, y); slot j of the scan for table choice;
+    // `boundary()` is called between two MCUs where a restart interval ends (ri = 0: never)
+    auto for_each_block = [&](auto &&fn, auto &&boundary) {
+        long mcu = 0;
         if (ns == 1) {
             const Plane &p = planes[sc.component[0]];
             for (int y = 0; y < p.uy; ++y)
-                for (int x = 0; x < p.ux; ++x) fn(0, p.at(x, y));
+                for (int x = 0; x < p.ux; ++x, ++mcu) {
+                    if (ri && mcu && mcu % ri == 0) boundary();
+                    fn(0, p.at(x, y));
+                }
         } else {
             for (int my = 0; my < mcuy; ++my)
-                for (int mx = 0; mx < mcux; ++mx)
+                for (int mx = 0; mx < mcux; ++mx, ++mcu) {
+                    if (ri && mcu && mcu % ri == 0) boundary();
                     for (int j = 0; j < ns; ++j) {
                         const Plane &p = planes[sc.component[j]];
                         for (int by = 0; by < p.fy; ++by)
                             for (int bx = 0; bx < p.fx; ++bx) fn(j, p.at(mx * p.fx + bx, my * p.fy + by));
                     }
+                }
         }
     };
 
     if (sc.band_lo == 0 && sc.refine) {          // DC refinement: one raw bit per block, no tables
         scan_header(out, sc, ids);
         Sink s; s.out = &out;
-        for_each_block([&](int, const int16_t *blk) { s.bits((unsigned)(blk[0] >> a) & 1u, 1); });
+        for_each_block([&](int, const int16_t *blk) { s.bits((unsigned)(blk[0] >> a) & 1u, 1); }, [&] { s.restart_marker(); });
         s.finish();
         return JPEG_AMD_OK;
     }
@@ -358,7 +377,7 @@ int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const s
                 pred[j] = high;
                 if (pass) { s.bits(cb[sc.dc[j]].code[binade], cb[sc.dc[j]].length[binade]); s.bits(tail, binade); }
                 else ++freq[sc.dc[j]][binade];
-            });
+            }, [&] { pred[0] = pred[1] = pred[2] = pred[3] = 0; if (pass) s.restart_marker(); });
             if (pass) { s.finish(); break; }
             bool used[4] = {false, false, false, false};
             for (int j = 0; j < ns; ++j) used[sc.dc[j]] = true;
@@ -380,7 +399,7 @@ int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const s
     std::vector<Token> tokens;
     std::vector<uint8_t> pool;                   // correction bits of the refinement pass
     auto eob = [&](uint32_t rb, uint32_t re) {   // extend the running EOB run or open a new one
-        if (!tokens.empty() && (tokens.back().sym & 0x0f) == 0 && tokens.back().sym != 0xf0) {
+        if (!tokens.empty() && tokens.back().ntail != 0xff && (tokens.back().sym & 0x0f) == 0 && tokens.back().sym != 0xf0) {
             Token &t = tokens.back();
             const unsigned count = (1u << (t.sym >> 4)) | t.tail;
             if (count < 4096) {
@@ -394,9 +413,15 @@ int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const s
         tokens.push_back({0x00, 0, 0, rb, re});
     };
     const Plane &p = planes[sc.component[0]];
+    long block_index = 0;
+    auto maybe_restart = [&] {                   // an EOB run never crosses a restart marker (T.81 G.1.2.2)
+        if (ri && block_index && block_index % ri == 0) tokens.push_back({0, 0xff, 0, 0, 0});
+        ++block_index;
+    };
     if (!sc.refine) {
         for (int y = 0; y < p.uy; ++y)
             for (int x = 0; x < p.ux; ++x) {
+                maybe_restart();
                 const int16_t *blk = p.at(x, y);
                 int zeroes = 0;
                 for (int z = sc.band_lo; z < sc.band_hi; ++z) {
@@ -414,6 +439,7 @@ int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const s
         const int mask = ~((1 << (a + 1)) - 1);
         for (int y = 0; y < p.uy; ++y)
             for (int x = 0; x < p.ux; ++x) {
+                maybe_restart();
                 const int16_t *blk = p.at(x, y);
                 int zeroes = 0;
                 // correction bits seen since the last symbol, cut into one chunk per completed
@@ -444,7 +470,7 @@ int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const s
     }
     long freq[256];
     std::memset(freq, 0, sizeof freq);
-    for (const Token &t : tokens) ++freq[t.sym];
+    for (const Token &t : tokens) if (t.ntail != 0xff) ++freq[t.sym];
     Codebook cb;
     if (!build_codebook(freq, cb)) return JPEG_AMD_EINVAL;
     std::vector<uint8_t> dht{(uint8_t)(0x10 | sc.ac[0])};
@@ -454,6 +480,7 @@ int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const s
     scan_header(out, sc, ids);
     Sink s; s.out = &out;
     for (const Token &t : tokens) {
+        if (t.ntail == 0xff) { s.restart_marker(); continue; }
         s.bits(cb.code[t.sym], cb.length[t.sym]);
         s.bits(t.tail, t.ntail);
         for (uint32_t r = t.ref_begin; r < t.ref_end; ++r) s.bits(pool[r], 1);
@@ -575,6 +602,12 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
     }
     int scale_x = 1, scale_y = 1;                // Layout.scale: max factor over the components
     for (const Plane &p : planes) { scale_x = std::max(scale_x, p.fx); scale_y = std::max(scale_y, p.fy); }
+    // Restart intervals are an EXTENSION: the reference's writer never emits DRI
+    // (frame->restart_interval = 0 reproduces it); with a value every scan is cut into intervals
+    // of that many MCUs, which this library's decoder then takes on several threads.
+    const int ri = frame->restart_interval;
+    if (ri < 0 || ri > 65535) return JPEG_AMD_EINVAL;
+    if (ri) { std::vector<uint8_t> b; put16(b, (unsigned)ri); segment(out, 0xdd, b); }
     const int mcux = (frame->width + 8 * scale_x - 1) / (8 * scale_x);
     const int mcuy = (frame->height + 8 * scale_y - 1) / (8 * scale_y);
     for (size_t g = 0; g < starts.size(); ++g) {
@@ -601,7 +634,7 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
             const jpeg_amd_scan &sc = scans[i];
             const int ns = sc.ncomponents;
             if (progressive) {
-                const int st = progressive_scan(out, sc, planes, frame->id, mcux, mcuy);
+                const int st = progressive_scan(out, sc, planes, frame->id, mcux, mcuy, ri);
                 if (st != JPEG_AMD_OK) return st;
                 continue;
             }
@@ -620,14 +653,23 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
                     s.dc_sel = sc.dc[j]; s.ac_sel = sc.ac[j];
                     if (emit) { s.dc = dcb + sc.dc[j]; s.ac = acb + sc.ac[j]; }
                 };
+                long mcu = 0;
+                auto boundary = [&] {
+                    if (ri && mcu && mcu % ri == 0) {
+                        pred[0] = pred[1] = pred[2] = pred[3] = 0;
+                        if (s.tokens) s.tokens->push_back(kRestartToken);
+                    }
+                    ++mcu;
+                };
                 if (ns == 1) {
                     const Plane &p = planes[sc.component[0]];
                     select(0);
                     for (int y = 0; y < p.uy; ++y)
-                        for (int x = 0; x < p.ux; ++x) encode_block(p.at(x, y), pred[0], s);
+                        for (int x = 0; x < p.ux; ++x) { boundary(); encode_block(p.at(x, y), pred[0], s); }
                 } else {
                     for (int my = 0; my < mcuy; ++my)
-                        for (int mx = 0; mx < mcux; ++mx)
+                        for (int mx = 0; mx < mcux; ++mx) {
+                            boundary();
                             for (int j = 0; j < ns; ++j) {
                                 const Plane &p = planes[sc.component[j]];
                                 select(j);
@@ -635,6 +677,7 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
                                     for (int bx = 0; bx < p.fx; ++bx)
                                         encode_block(p.at(mx * p.fx + bx, my * p.fy + by), pred[j], s);
                             }
+                        }
                 }
                 if (emit) s.finish();
             };

@@ -295,3 +295,36 @@ def test_eob_runs_longer_than_4096_blocks_are_split():
     i = raw.rfind(b"\xff\xc4")
     dht = raw[i + 4:i + 2 + (raw[i + 2] << 8 | raw[i + 3])]
     assert 0xc0 in dht[17:]                                # EOB12: a run of 4096 was coded
+
+
+@pytest.mark.parametrize("ri", [1, 5, 64])
+@pytest.mark.parametrize("kind", ["sequential", "separate", "progressive"])
+def test_restart_intervals_written_by_the_library_round_trip(ri, kind):
+    """frame.restart_interval (an extension: the reference's writer never emits DRI): DRI + RSTm
+    markers in every scan kind; the sequential and the interval-parallel decoder give the planes
+    back, and an EOB run never crosses a marker."""
+    rng = np.random.default_rng(ri)
+    progressive = kind == "progressive"
+    info = _frame(150, 90, [(2, 2), (1, 1), (1, 1)], 2 if progressive else 0)
+    info.restart_interval = ri
+    planes = _random_planes(info, rng, 0.05)
+    if kind == "sequential":
+        scans = [[(0, 0, 0), (1, 1, 1), (2, 1, 1)]]
+    elif kind == "separate":
+        scans = [[(0, 0, 0)], [(1, 1, 1)], [(2, 1, 1)]]
+    else:
+        scans = [Scan.progressive_dc((0, 0), (1, 1), (2, 1), bits=1), Scan.progressive_dc_refine(0, 1, 2, bit=0)]
+        for c in range(3):
+            scans += [Scan.progressive_ac((c, c & 1), (1, 64), bits=1), Scan.progressive_ac_refine((c, c & 1), (1, 64), bit=0)]
+    out = _round_trip(info, planes, scans)
+    raw = bytes(out)
+    assert raw.count(b"\xff\xdd\x00\x04") == 1
+    # the interval-parallel decoder agrees
+    back = [np.zeros_like(p) for p in planes]
+    q = np.zeros((4, 64), np.uint16)
+    info2 = _lib.FrameInfo()
+    assert _lib.lib().jpeg_amd_jpeg_decode_spectral_mt(out.ctypes.data, out.size, _lib.ptr_array([p.ctypes.data for p in back]),
+                                                       q.ctypes.data, C.byref(info2), 4) == 0
+    assert info2.restart_interval == ri
+    for a, b in zip(planes, back):
+        assert (a == b).all()

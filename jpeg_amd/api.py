@@ -234,7 +234,7 @@ class Spectral:
     def host_planes(self) -> List[np.ndarray]:
         return [p.cpu().numpy() for p in self.planes]
 
-    def compress(self, scans, process: str = "baseline", metadata=None, path=None) -> bytes:
+    def compress(self, scans, process: str = "baseline", metadata=None, path=None, restart_interval: int = 0) -> bytes:
         """Spectral.compress(stream:) / compress(path:) -- encode.swift:1918-1972, os.swift:330.
         scans: the layout's scan progression -- Scan objects, or plain lists of (plane index, dc
         selector, ac selector) for sequential scans; metadata: see _metadata_array.  The coefficient planes come back to the host and are entropy-coded
@@ -244,6 +244,7 @@ class Spectral:
         info.precision, info.ncomponents = self.layout.precision, self.layout.count
         info.process = {"baseline": 0, "extended": 1, "progressive": 2}[process]
         info.scale_x, info.scale_y = self.layout.scale
+        info.restart_interval = int(restart_interval)   # extension: DRI + RSTm (0 = like the reference)
         keys = []
         for p, (key, comp) in enumerate(zip(self.layout.recognized, self.layout.planes)):
             info.id[p] = int(key)
@@ -533,10 +534,11 @@ class Rectangular:
         return Spectral(ctx, size, layout, out, tables, q)
 
     def compress(self, quanta: Dict[int, Sequence[int]], scans, process: str = "baseline", metadata=None,
-                 path=None) -> bytes:
+                 path=None, restart_interval: int = 0) -> bytes:
         """Rectangular.compress(stream:quanta:) / compress(path:quanta:) -- encode.swift:2031,
         os.swift:412: decomposed().fdct(quanta:).compress(...)."""
-        return self.decomposed().fdct(quanta).compress(scans, process=process, metadata=metadata, path=path)
+        return self.decomposed().fdct(quanta).compress(scans, process=process, metadata=metadata, path=path,
+                                                         restart_interval=restart_interval)
 
     def host_values(self) -> np.ndarray:
         return self.values.cpu().numpy().view(np.uint16)

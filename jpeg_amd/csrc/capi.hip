@@ -841,6 +841,8 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
         });
         return JPEG_AMD_OK;
     };
+    std::thread drainer;
+    int drain_status = JPEG_AMD_OK;
     for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
         char *host = static_cast<char *>(ctx->file_pinned[slot]);
@@ -868,6 +870,7 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
             status[i] = st;
         });
         for (int st : status) if (st != JPEG_AMD_OK) result = st;
+        if (drainer.joinable()) { drainer.join(); if (drain_status != JPEG_AMD_OK) result = drain_status; }
         if (result != JPEG_AMD_OK) break;
         // the device side of chunk k (asynchronous); the host moves on to chunk k + 1 meanwhile.
         // Device slot `slot` was last read by the download of chunk k - 2, finished before drain(k - 2)
@@ -887,8 +890,15 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
         JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
         JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
         JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->file_d2h));
-        if (k >= 1) JA_TRY(drain(k - 1));
+        // chunk k - 1 is copied out by a helper thread WHILE the host decodes chunk k + 1; it has
+        // to be finished before chunk k + 1 is submitted (its download lands in the same pinned slot)
+        if (k >= 1) {
+            drain_status = JPEG_AMD_OK;
+            drainer = std::thread([&, k] { (void)hipSetDevice(ctx->device); drain_status = drain(k - 1); });
+        }
     }
+    if (drainer.joinable()) drainer.join();
+    if (result == JPEG_AMD_OK) result = drain_status;
     if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->file_d2h); return result; }
     JA_TRY(drain(nchunks - 1));
     return JPEG_AMD_OK;

@@ -992,22 +992,30 @@ int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const
     int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
     JA_TRY(bag.alloc(npx * chunk, (void **)&d_px));
     for (int c = 0; c < nc; ++c) JA_TRY(bag.alloc(plane[c] * 2 * chunk, (void **)&d_coef[c]));
-    std::vector<std::vector<int16_t>> h_coef((size_t)nc);
-    for (int c = 0; c < nc; ++c) h_coef[c].resize(plane[c] * chunk);
-
-    for (int base = 0; base < n_images; base += chunk) {
-        const int m = std::min(chunk, n_images - base);
-        for (int i = 0; i < m; ++i)
-            JA_HIP(ctx, hipMemcpyAsync(d_px + npx * i, h_pixels + (size_t)(base + i) * pixel_stride, npx, hipMemcpyHostToDevice, ctx->stream));
-        JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, d_px, npx, color, d_q, 0, ntables, d_coef, stride));
+    // two pinned host slots for the coefficient planes: the host threads entropy-code chunk k - 1
+    // out of one while the device encodes chunk k into the other
+    struct Pinned {
+        std::vector<void *> p;
+        ~Pinned() { for (void *q : p) (void)hipHostFree(q); }
+        void *get(size_t bytes) { void *q = nullptr; if (hipHostMalloc(&q, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr; p.push_back(q); return q; }
+    } pinned;
+    int16_t *h_coef[2][JPEG_AMD_MAX_PLANES] = {};
+    hipEvent_t ready[2] = {nullptr, nullptr};
+    struct Events { hipEvent_t *e; ~Events() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } events{ready};
+    for (int sl = 0; sl < 2; ++sl) {
         for (int c = 0; c < nc; ++c)
-            JA_HIP(ctx, hipMemcpyAsync(h_coef[c].data(), d_coef[c], plane[c] * 2 * m, hipMemcpyDeviceToHost, ctx->stream));
-        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (!(h_coef[sl][c] = static_cast<int16_t *>(pinned.get(plane[c] * 2 * chunk)))) return JPEG_AMD_ENOMEM;
+        JA_HIP(ctx, hipEventCreateWithFlags(&ready[sl], hipEventDisableTiming));
+    }
+    const int nchunks = (n_images + chunk - 1) / chunk;
+    auto entropy_code = [&](int k) -> int {                  // chunk k is back in its pinned slot
+        const int sl = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
+        JA_HIP(ctx, hipEventSynchronize(ready[sl]));
         std::vector<int> status((size_t)m, JPEG_AMD_OK);
         auto work = [&](int t) {
             for (int i = t; i < m; i += nthreads) {
                 const int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
-                for (int c = 0; c < nc; ++c) planes[c] = h_coef[c].data() + plane[c] * i;
+                for (int c = 0; c < nc; ++c) planes[c] = h_coef[sl][c] + plane[c] * i;
                 status[i] = jpeg_amd_jpeg_encode_spectral(frame, quanta_key, planes, h_quanta, h_quanta_keys, ntables, scans, nscans,
                                                           metadata, nmetadata, h_out + (size_t)(base + i) * out_stride, out_stride,
                                                           &nbytes[base + i]);
@@ -1018,7 +1026,23 @@ int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const
         work(0);
         for (std::thread &th : pool) th.join();
         for (int st : status) if (st != JPEG_AMD_OK) return st;   // EINVAL with nbytes[i] > out_stride: buffer too small
+        return JPEG_AMD_OK;
+    };
+    for (int k = 0; k < nchunks; ++k) {
+        const int sl = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
+        // device side of chunk k, asynchronous (slot sl was consumed by entropy_code(k - 2))
+        for (int i = 0; i < m; ++i)
+            JA_HIP(ctx, hipMemcpyAsync(d_px + npx * i, h_pixels + (size_t)(base + i) * pixel_stride, npx, hipMemcpyHostToDevice, ctx->stream));
+        JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, d_px, npx, color, d_q, 0, ntables, d_coef, stride));
+        for (int c = 0; c < nc; ++c)
+            JA_HIP(ctx, hipMemcpyAsync(h_coef[sl][c], d_coef[c], plane[c] * 2 * m, hipMemcpyDeviceToHost, ctx->stream));
+        JA_HIP(ctx, hipEventRecord(ready[sl], ctx->stream));
+        if (k >= 1) {
+            const int st = entropy_code(k - 1);               // ... while the host writes the files of chunk k - 1
+            if (st != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); return st; }
+        }
     }
+    JA_TRY(entropy_code(nchunks - 1));
     return JPEG_AMD_OK;
 }
 

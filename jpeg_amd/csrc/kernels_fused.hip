@@ -39,7 +39,8 @@ constexpr int kThreads = 256;
 // trunc(clamp(x, 0, 255)) == saturating round-to-nearest(x + kTruncBias) for the R and B
 // channel values x = y + m c (see k_luma_fused and tests/test_colour_rounding.py)
 constexpr float kTruncBias = -0.5f + 0.0009765625f;
-constexpr int TBX = 32;  // luma blocks per tile row   (tile = 256 x 64 px)
+// a strip is BX x BY luma blocks, BX * BY == 64 (one block per work-item): 32 x 2, or 16 x 4 for
+// images whose width leaves the last 32-block strip half empty (1920 px = 7.5 strips of 32)
 
 // ---------------------------------------------------------------------------------------
 // K1: chroma planes -> uint8 samples.  blockIdx.z selects the plane (same geometry).
@@ -140,10 +141,9 @@ __device__ __forceinline__ void lerp_row_2x(const float (&p)[6], float (&o)[8])
 // FAST: W % 16 == 0 and 16-byte aligned rows, so every 16-byte chunk of a row segment is either
 // entirely inside the image or entirely outside (no byte-wise tail code in the hot path).
 //
-// Persistent, fully independent WAVES.  The unit of work is a strip of 32 x 2 luma blocks
-// (256 x 16 px); wave g of the launch walks strips g, g + nwaves, ...  Lanes 0..31 are 32
-// consecutive blocks of the strip's first block row, lanes 32..63 the same columns of the
-// second.  Everything a wave touches in LDS is private to it: there is no workgroup barrier,
+// Persistent, fully independent WAVES.  The unit of work is a strip of BX x BY luma blocks
+// (32 x 2 = 256 x 16 px, or 16 x 4 = 128 x 32 px); wave g of the launch walks strips g,
+// g + nwaves, ...  Lane l is block (l % BX, l / BX) of the strip (row-major).  Everything a wave touches in LDS is private to it: there is no workgroup barrier,
 // waves drift apart and their memory and arithmetic phases interleave on the SIMD.
 //
 // What bounds this kernel is how many waves are READY to issue, not HBM: one wave alone issues
@@ -195,12 +195,13 @@ __device__ unsigned long long g_phase_cycles[4096 * 8];
 #define JA_PHASE(i)
 #endif
 
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST>
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX>
 __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
 {
+    constexpr int BY = 64 / BX;                          // block rows per strip
     constexpr int NW = kThreads / 64;                    // waves per workgroup
-    constexpr int CW = TBX * 8 / SX;                     // chroma samples per strip row
-    constexpr int CR = 2 * 8 / SY;                       // chroma rows under a strip (2 block rows)
+    constexpr int CW = BX * 8 / SX;                      // chroma samples per strip row
+    constexpr int CR = BY * 8 / SY;                      // chroma rows under a strip
     constexpr int HX = SX == 2 ? 4 : 0;                  // halo bytes per side (keeps dword alignment)
     constexpr int HY = SY == 2 ? 1 : 0;
     constexpr int PITCH = (CW + 2 * HX) / 4;             // dwords per LDS row
@@ -210,10 +211,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     // their samples as bytes in LDS ([dword][lane], like k_encode_fused) and then does the luma block
     constexpr bool INTHREAD = CHROMA && SX == 1 && SY == 1;
     constexpr int PLANE = (CHROMA && !INTHREAD) ? ROWS * PITCH : 1;
-    constexpr int SEG_DW = TBX * 6;                      // one 32-block row segment: 768 B
+    constexpr int SEG_DW = BX * 6;                       // one pixel row of one block row: 24 B per block
+    constexpr int CPS = SEG_DW / 4;                      // 16-byte chunks per such segment
     constexpr int NTAB = INTHREAD ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
-    __shared__ __attribute__((aligned(16))) uint32_t stage[NW][2 * SEG_DW]; // one pixel row x 2 block rows
+    __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
     __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
 
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sc);
     float *sq = sqw[wave][0];
 
-    // strip s -> image, strip row (2 block rows), strip column (32 blocks)
+    // strip s -> image, strip row (BY block rows), strip column (BX blocks)
     auto locate = [&](int s, int &img, int &syi, int &sxi) {
         img = s / a.tiles_per_image;
         const int rem = s - img * a.tiles_per_image;
@@ -246,14 +248,14 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         if constexpr (INTHREAD) {
             if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
         }
-        if (sxi * TBX + TBX <= a.ux && 2 * syi + 2 <= a.uy) {
+        if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {
             // interior strip (wave-uniform test): the block index is scalar, only the lane's
             // place inside an 8-block group (and its swizzled chunk) is per lane
             const uint32_t l3 = lane >> 3;
             const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);  // even i; odd i: chunk ^ 4
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const uint32_t blk0 = (uint32_t)(2 * syi + (i >> 2)) * a.ux + sxi * TBX + 8 * (i & 3);
+                const uint32_t blk0 = (uint32_t)(BY * syi + i / (BX / 8)) * a.ux + sxi * BX + 8 * (i % (BX / 8));
                 const uint64_t sb = reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7);
                 lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
             }
@@ -261,8 +263,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int b = 8 * i + (lane >> 3);  // block within the strip: column b & 31, row b >> 5
-            const int bx = sxi * TBX + (b & 31), by = 2 * syi + (b >> 5);
+            const int b = 8 * i + (lane >> 3);  // block within the strip: column b % BX, row b / BX
+            const int bx = sxi * BX + (b & (BX - 1)), by = BY * syi + (int)((unsigned)b / BX);
             // blocks outside the plane fetch block 0; the store predicate discards their pixels
             const uint32_t blk = (bx < a.ux && by < a.uy) ? (uint32_t)by * a.ux + bx : 0u;
             const int c = (lane & 7) ^ ((b >> 1) & 7);
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         // cheap to recompute, but hoisted out of this loop it would pin ~60 VGPRs for good.
         int lane = lane0;
         asm volatile("" : "+v"(lane));
-        const int lbx = lane & (TBX - 1), seg = lane >> 5;
+        const int lbx = lane & (BX - 1), seg = (int)((unsigned)lane / BX);
         int img, syi, sxi;
         locate(s, img, syi, sxi);
 
@@ -356,15 +358,32 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         const int cx0 = sxi * CW, cy0 = syi * CR;
         const int pwd = a.pw_c >> 2;
         if constexpr (CHROMA && !INTHREAD) {
-            const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + lane, 0), pwd - 1);
-            if (lane < PITCH) {
+            // rows of a narrow tile are packed RPI to a transfer (the LDS image is lane-linear and the
+            // tile rows are contiguous): 12 transfers instead of 36 for a 16 x 4 strip of 4:2:0
+            constexpr int RPI = (ROWS % (64 / PITCH) == 0) ? 64 / PITCH : 1;
+            if constexpr (RPI == 1) {
+                const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + lane, 0), pwd - 1);
+                if (lane < PITCH) {
 #pragma unroll
-                for (int vr = 0; vr < 2 * ROWS; ++vr) {
-                    const int pl = vr >= ROWS ? 1 : 0;
-                    const int gy = min(max(cy0 - HY + vr - pl * ROWS, 0), a.ph_c - 1);
-                    const uint64_t rowbase = reinterpret_cast<uint64_t>((pl ? a.cr : a.cb) + img * a.c_stride) +
-                                             (uint64_t)((uint32_t)gy * (uint32_t)a.pw_c);
-                    lds_dma4_s(rowbase, coff, sc_lds + 4 * PITCH * vr);
+                    for (int vr = 0; vr < 2 * ROWS; ++vr) {
+                        const int pl = vr >= ROWS ? 1 : 0;
+                        const int gy = min(max(cy0 - HY + vr - pl * ROWS, 0), a.ph_c - 1);
+                        const uint64_t rowbase = reinterpret_cast<uint64_t>((pl ? a.cr : a.cb) + img * a.c_stride) +
+                                                 (uint64_t)((uint32_t)gy * (uint32_t)a.pw_c);
+                        lds_dma4_s(rowbase, coff, sc_lds + 4 * PITCH * vr);
+                    }
+                }
+            } else {
+                const int rin = (int)((unsigned)lane / PITCH), col = lane - rin * PITCH;
+                const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + col, 0), pwd - 1);
+                if (lane < RPI * PITCH) {
+#pragma unroll
+                    for (int k = 0; k < 2 * ROWS / RPI; ++k) {
+                        const int pl = k * RPI >= ROWS ? 1 : 0;   // ROWS % RPI == 0: a transfer never straddles the planes
+                        const int gy = min(max(cy0 - HY + k * RPI - pl * ROWS + rin, 0), a.ph_c - 1);
+                        const uint64_t planebase = reinterpret_cast<uint64_t>((pl ? a.cr : a.cb) + img * a.c_stride);
+                        lds_dma4_s(planebase, (uint32_t)gy * (uint32_t)a.pw_c + coff, sc_lds + 4 * PITCH * RPI * k);
+                    }
                 }
             }
         }
@@ -444,22 +463,26 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             for (int pl = 0; pl < 2; ++pl) { hrow(pl, 0, hw[pl][0]); hrow(pl, 1, hw[pl][1]); }
         }
 
-        // ---- store geometry: per pixel row the strip's 2 segments are 96 chunks of 16 B; a lane
+        // ---- store geometry: per pixel row the strip's BY segments are 96 chunks of 16 B; a lane
         //      stores chunk `lane` (and lanes 0..31 also chunk 64 + lane).  Byte offsets relative to
-        //      the strip's first pixel are computed once; the row advance is scalar. ----
-        const int tile_px = min(TBX * 8, a.W - TBX * 8 * sxi);  // pixels of this strip inside the image
+        //      the strip's first pixel are computed once; the row advance is scalar.  Both store
+        //      instructions of a row cover whole 128-byte lines (segments are 768 or 384 B). ----
+        const int tile_px = min(BX * 8, a.W - BX * 8 * sxi);    // pixels of this strip inside the image
         const int nb = 3 * tile_px;                              // bytes per row segment to write
         const uint32_t pitch = 3u * a.W;
-        uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(16 * syi) * a.W + TBX * 8 * sxi) * 3;
-        const int sg0 = lane >= 48 ? 1 : 0, j0 = lane - 48 * sg0, j1 = 16 + lane;
-        const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = 8u * pitch + 16u * j1;
-        const bool full = 16 * syi + 16 <= a.H && tile_px == TBX * 8;   // wave-uniform
+        uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(8 * BY * syi) * a.W + BX * 8 * sxi) * 3;
+        int sg0, sg1;   // segments of chunk `lane` and of chunk 64 + lane (the latter for lanes 0..31)
+        if constexpr (BX == 32) { sg0 = lane >= 48 ? 1 : 0; sg1 = 1; }
+        else { sg0 = (int)((unsigned)lane / CPS); sg1 = (int)((64u + (unsigned)lane) / CPS); }
+        const int j0 = lane - CPS * sg0, j1 = 64 + lane - CPS * sg1;
+        const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = sg1 * 8u * pitch + 16u * j1;
+        const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
         stores_behind_dma = (FAST && full) ? 16 : 0;
         JA_PHASE(4)
 
 #pragma unroll
-        for (int y = 0; y < 8; ++y) {  // pixel row y of both block rows
+        for (int y = 0; y < 8; ++y) {  // pixel row y of every block row of the strip
             if ((y & 1) == 0) __builtin_amdgcn_sched_barrier(0);
             float cv[2][8];
             if constexpr (CHROMA) {
@@ -549,8 +572,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                     put(rowp + voff0, v0, j0);
                     if (lane < 32) put(rowp + voff1, v1, j1);
                 } else {
-                    if (col0 && 16 * syi + 8 * sg0 + y < a.H) put(rowp + voff0, v0, j0);
-                    if (col1 && 16 * syi + 8 + y < a.H) put(rowp + voff1, v1, j1);
+                    if (col0 && 8 * BY * syi + 8 * sg0 + y < a.H) put(rowp + voff0, v0, j0);
+                    if (col1 && 8 * BY * syi + 8 * sg1 + y < a.H) put(rowp + voff1, v1, j1);
                 }
             }
         }
@@ -566,12 +589,12 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kT
 
 // Persistent grid = what is resident at once: workgroups per CU (LDS- and VGPR-bound, differs per
 // instantiation: 3 for 4:2:0 and grey, 2 for the variants with a full-width chroma tile) x CUs.
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST>
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX>
 int resident_workgroups()
 {
     static int cached = 0;  // one per instantiation
     if (cached == 0) {
-        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST>;
+        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX>;
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -581,13 +604,13 @@ int resident_workgroups()
     return cached;
 }
 
-template <int MODE, bool FAST>
+template <int MODE, bool FAST, int BX>
 hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, int sy, bool chroma)
 {
 #define JA_K(SX_, SY_, CH_)                                                          \
     {                                                                                \
-        auto k = k_luma_fused<SX_, SY_, MODE, CH_, FAST>;                            \
-        const int cap = resident_workgroups<SX_, SY_, MODE, CH_, FAST>();            \
+        auto k = k_luma_fused<SX_, SY_, MODE, CH_, FAST, BX>;                        \
+        const int cap = resident_workgroups<SX_, SY_, MODE, CH_, FAST, BX>();        \
         hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a); \
     }
     if (!chroma) JA_K(1, 1, false)
@@ -597,6 +620,20 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
     else JA_K(1, 1, true)
 #undef JA_K
     return hipGetLastError();
+}
+
+// Strip shape: 32 x 2 blocks unless 16 x 4 covers the plane with fewer strips (a half-empty strip
+// costs as much as a full one: 1920 x 1080 is 7.5 x 68 strips of 32 x 2 but exactly 15 x 34 of
+// 16 x 4).  Only the 4:2:0 / 4:4:4 / grey kernels come in both shapes: the 4:2:2 and 4:4:0 chroma
+// tiles of a 16 x 4 strip would need 64 row transfers.
+inline int strip_width(int ux, int uy, int sx, int sy)
+{
+#ifdef JA_X_FORCE_BX
+    return JA_X_FORCE_BX;
+#endif
+    if (sx != sy) return 32;
+    const long wide = (long)((ux + 31) / 32) * ((uy + 1) / 2), narrow = (long)((ux + 15) / 16) * ((uy + 3) / 4);
+    return narrow < wide ? 16 : 32;
 }
 
 }  // namespace
@@ -677,9 +714,11 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     la.ux = L.units_x[0]; la.uy = L.units_y[0];
     la.W = L.width; la.H = L.height;
     la.out = d_pixels; la.out_stride = pixel_stride;
-    // unit of work: strip of 32 x 2 luma blocks; persistent waves, 3 per SIMD (VGPR- and LDS-bound)
-    la.tiles_x = (la.ux + TBX - 1) / TBX;
-    const int strips_y = (la.uy + 1) / 2;
+    // unit of work: strip of 32 x 2 (or 16 x 4) luma blocks; persistent waves, 3 per SIMD (VGPR- and LDS-bound)
+    const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;
+    const int bx = strip_width(la.ux, la.uy, sx, sy), by = 64 / bx;
+    la.tiles_x = (la.ux + bx - 1) / bx;
+    const int strips_y = (la.uy + by - 1) / by;
     la.tiles_per_image = la.tiles_x * strips_y;
     la.total_tiles = la.tiles_per_image * n_images;
     if (la.total_tiles == 0) return hipSuccess;
@@ -690,14 +729,19 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     // fewer waves, no thin last round -- measured 4 % slower; 2 instead of 3 workgroups per CU
     // is 3.5 % slower.)
     const int wgs = (la.total_tiles + 3) / 4;
-    const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;
     const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-    if (fast)
-        return rgb ? launch_luma<1, true>(stream, wgs, la, sx, sy, chroma)
-                   : launch_luma<0, true>(stream, wgs, la, sx, sy, chroma);
-    return rgb ? launch_luma<1, false>(stream, wgs, la, sx, sy, chroma)
-               : launch_luma<0, false>(stream, wgs, la, sx, sy, chroma);
+#define JA_L(BX_)                                                                     \
+    {                                                                                 \
+        if (fast)                                                                     \
+            return rgb ? launch_luma<1, true, BX_>(stream, wgs, la, sx, sy, chroma)   \
+                       : launch_luma<0, true, BX_>(stream, wgs, la, sx, sy, chroma);  \
+        return rgb ? launch_luma<1, false, BX_>(stream, wgs, la, sx, sy, chroma)      \
+                   : launch_luma<0, false, BX_>(stream, wgs, la, sx, sy, chroma);     \
+    }
+    if (bx == 16) JA_L(16)
+    JA_L(32)
+#undef JA_L
 }
 
 }  // namespace jpeg_amd

@@ -585,425 +585,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
 #endif
 }
 
-// ---------------------------------------------------------------------------------------
-// K3: 4:2:0 in ONE launch.  k_chroma_idct's work becomes tasks of the same persistent waves that
-// walk the luma strips, a few chroma block rows AHEAD of them, so that the chroma samples go from
-// producer to consumer through the L2 of one XCD instead of through a second launch.
-//
-// The image is cut into slices of `slice_rows` luma strip rows (= chroma block rows).  A slice is
-// worked on by the waves of ONE XCD (they find out which one they are from HW_REG_XCC_ID): the
-// XCD's waves draw tickets from the XCD's own counter, ticket t = (k, j): j-th task of the k-th
-// slice this XCD works on; the wave that draws j == 0 claims the next free slice for the XCD
-// (the only cross-XCD atomic).  Task order inside a slice: `lead` chroma block rows first, then
-// per luma strip row its strips followed by one more chroma block row.  A chroma task (64 blocks
-// of one plane) stores its samples with plain stores, waits for them (s_waitcnt vmcnt(0): they
-// are in the XCD's L2 then) and increments the row's counter; a luma task polls the counters of
-// the three chroma block rows it reads (sc1 loads: L1-bypassing, served by the same L2) before it
-// requests its chroma tile, also with sc1.  tools/probe_xcd.hip checks exactly this protocol.
-// Every wait targets work with an EARLIER ticket of the same XCD, held by a running wave that
-// itself never waits on later tickets: no deadlock.  Spins are bounded all the same; a time-out
-// sets the error word of the control block.
-// ---------------------------------------------------------------------------------------
-struct OnePassArgs {
-    LumaArgs l;
-    int rows;                              // luma strip rows (= chroma block rows) per image
-    int slice_rows, slices_per_image, nslices;
-    int cu;                                // chroma units (64 blocks) per plane per chroma block row
-    int lead;                              // chroma block rows transformed ahead of the luma rows
-    int max_claims;                        // nslices + 2: slots of mine[] per XCD
-    int dump_dword;                        // 4 KiB of the control block that swallows the stores of blocks past the plane
-    uint32_t *ctl;                         // control block, zero at launch
-};
-constexpr int kCtlTicketStride = 32;       // dwords: one 128-byte line per XCD
-constexpr int kCtlNext = 16 * kCtlTicketStride;   // next free slice; [+1] error word
-constexpr int kCtlMine = kCtlNext + 32;    // mine[16][max_claims]: slice + 1 of the XCD's k-th claim; then cnt[nslices][slice_rows + 2]
-constexpr uint32_t kEndMark = 0xffffffffu;
-constexpr int kSpinLimit = 1 << 18;
-
-__device__ __forceinline__ void lds_dma4_s_sc1(uint64_t sbase, uint32_t voff, uint32_t lds)
-{
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0 sc1" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kThreads, 3) void k_decode_onepass(OnePassArgs oa)
-{
-    const LumaArgs &a = oa.l;
-    constexpr int BX = 32, SX = 2, SY = 2;
-    constexpr int NW = kThreads / 64;
-    constexpr int CW = BX * 8 / SX, CR = 2 * 8 / SY, HX = 4, HY = 1;
-    constexpr int PITCH = (CW + 2 * HX) / 4, ROWS = CR + 2 * HY, PLANE = ROWS * PITCH;
-    constexpr int SEG_DW = BX * 6;
-    __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];
-    __shared__ __attribute__((aligned(16))) uint32_t stage[NW][2 * SEG_DW];
-    __shared__ uint32_t scw[NW][2 * PLANE];
-    __shared__ float sqw[NW][3][64];
-
-    const int lane0 = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *stage_w = stage[wave];
-    uint32_t *coef_w = coefbuf[wave];
-    const uint32_t coef_lds = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)coef_w);
-    uint32_t *sc = scw[wave];
-    const uint32_t sc_lds = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sc);
-
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 15u;
-    uint32_t *const ticket = oa.ctl + xcc * kCtlTicketStride;
-    uint32_t *const mine = oa.ctl + kCtlMine + xcc * oa.max_claims;
-    uint32_t *const cnt_base = oa.ctl + kCtlMine + 16 * oa.max_claims;
-    uint32_t *const err = oa.ctl + kCtlNext + 1;
-
-#ifdef JA_X_1P_NOCHROMA   // experiment: the luma strips alone under the ticket scheduler
-    const int nL = a.tiles_x, nC = 0, G = nL, head = 0;
-#else
-    const int nL = a.tiles_x, nC = 2 * oa.cu, G = nL + nC, head = oa.lead * nC;
-#endif
-    const uint32_t tps = (uint32_t)(head + oa.slice_rows * G);
-
-    enum { END = 0, LUMA = 1, CHROMA = 2, NOP = 3 };
-    struct Task { int kind, img, slice, lo, row, idx; };
-    int known_k = -1;
-    uint32_t known_slice = kEndMark;
-
-    // ticket -> task (everything wave-uniform)
-    auto decode = [&](uint32_t t) -> Task {
-        Task k{END, 0, 0, 0, 0, 0};
-        const uint32_t kk = t / tps, j = t - kk * tps;
-        if (kk + 1 >= (uint32_t)oa.max_claims) return k;
-        if ((int)kk != known_k) {
-            // The wave that draws the first ticket of the XCD's kk-th slice claims a slice for the
-            // (kk + 1)-th, a whole slice ahead of need (the only cross-XCD atomic); the very first
-            // ticket also claims the XCD's first slice.
-            auto claim = [&](uint32_t slot) {
-                uint32_t sl = 0;
-                if (lane0 == 0) sl = __hip_atomic_fetch_add(oa.ctl + kCtlNext, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sl = __builtin_amdgcn_readfirstlane(sl);
-                const uint32_t val = sl < (uint32_t)oa.nslices ? sl + 1 : kEndMark;
-                if (lane0 == 0) __hip_atomic_store(mine + slot, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            };
-            if (j == 0) {
-                if (kk == 0) claim(0);
-                claim(kk + 1);
-            }
-            uint32_t v;
-            {
-                int spins = 0;
-                for (;;) {
-                    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(mine + kk) : "memory");
-                    if (v != 0) break;
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++spins > kSpinLimit) { if (lane0 == 0) *err = 1; v = kEndMark; break; }
-                }
-            }
-            known_k = (int)kk; known_slice = v;
-        }
-        if (known_slice == kEndMark) return k;
-        const int slice = (int)known_slice - 1;
-        k.slice = slice;
-        k.img = slice / oa.slices_per_image;
-        const int si = slice - k.img * oa.slices_per_image;
-        k.lo = si * oa.slice_rows;
-        const int hi = min(k.lo + oa.slice_rows, oa.rows), n = hi - k.lo;
-        const int c_end = min(hi + 1, oa.rows);   // chroma block rows [lo - 1, c_end) serve this slice
-        int c, unit;
-        if ((int)j < head) {
-            const int rel = (int)j / nC;
-            unit = (int)j - rel * nC; c = k.lo - 1 + rel;
-        } else {
-            const int u = (int)j - head, g = u / G, v = u - g * G;
-            if (g >= n) { k.kind = NOP; return k; }
-            if (v < nL) { k.kind = LUMA; k.row = k.lo + g; k.idx = v; return k; }
-            unit = v - nL; c = k.lo - 1 + oa.lead + g;
-        }
-        if (c < 0 || c >= c_end) { k.kind = NOP; return k; }
-#ifdef JA_X_1P_NOCHROMA
-        k.kind = NOP; return k;
-#endif
-        k.kind = CHROMA; k.row = c; k.idx = unit;
-        return k;
-    };
-
-    // LDS-DMA of a task's 64 coefficient blocks; slot u = 64 i + lane holds chunk
-    // (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3 (as in k_luma_fused)
-    auto dma_task = [&](const Task &k, int lane) {
-        if (k.kind != LUMA && k.kind != CHROMA) return;
-        const int16_t *base;
-        int ux, uy, bx0, by0, per_row;
-        if (k.kind == LUMA) {
-            base = a.coef + k.img * a.coef_stride; ux = a.ux; uy = a.uy; bx0 = k.idx * BX; by0 = 2 * k.row; per_row = BX;
-        } else {
-            const int pl = k.idx >= oa.cu ? 1 : 0;
-            base = a.ccoef[pl] + k.img * a.ccoef_stride[pl];
-            ux = a.pw_c >> 3; uy = a.ph_c >> 3; bx0 = (k.idx - pl * oa.cu) * 64; by0 = k.row; per_row = 64;
-        }
-        const int nrows = 64 / per_row;
-        if (bx0 + per_row <= ux && by0 + nrows <= uy) {
-            const uint32_t l3 = lane >> 3;
-            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int b = 8 * i;
-                const uint32_t blk0 = (uint32_t)(by0 + (k.kind == LUMA ? (i >> 2) : 0)) * ux + bx0 + (k.kind == LUMA ? (b & 31) : b);
-                const uint64_t sb = reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7);
-                lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int b = 8 * i + (lane >> 3);
-            const int bx = bx0 + (k.kind == LUMA ? (b & 31) : b), by = by0 + (k.kind == LUMA ? (b >> 5) : 0);
-            const uint32_t blk = (bx < ux && by < uy) ? (uint32_t)by * ux + bx : 0u;
-            const int c = (lane & 7) ^ ((b >> 1) & 7);
-            const char *g = reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c);
-            lds_dma16(g, coef_lds + 1024 * i);
-        }
-    };
-    // the task fields ARE wave-uniform; tell the compiler (scalar registers, scalar address arithmetic)
-    auto uniform = [](const Task &k) -> Task {
-        Task u;
-        u.kind = __builtin_amdgcn_readfirstlane(k.kind); u.img = __builtin_amdgcn_readfirstlane(k.img);
-        u.slice = __builtin_amdgcn_readfirstlane(k.slice); u.lo = __builtin_amdgcn_readfirstlane(k.lo);
-        u.row = __builtin_amdgcn_readfirstlane(k.row); u.idx = __builtin_amdgcn_readfirstlane(k.idx);
-        return u;
-    };
-    // Tickets.  take_sync: draw and wait (prologue, after a NOP).  take_async: lane 0 issues the
-    // atomic from inline asm, so the compiler inserts no wait of its own (a compiler-placed
-    // vmcnt wait for the returned value would also wait for every pixel store in flight); the
-    // value is read only behind one of the explicit s_waitcnt below, which name the ticket
-    // register as an operand.  VM operations retire in issue order: "at most N outstanding"
-    // proves the atomic done when exactly N younger operations have been issued.
-    auto take_sync = [&]() -> uint32_t {
-        uint32_t t = 0;
-        if (lane0 == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return __builtin_amdgcn_readfirstlane(t);
-    };
-    auto take_async = [&](uint32_t &tv) {
-        const uint32_t zero = 0, one = 1;
-        if (lane0 == 0)
-            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(tv) : "v"(zero), "v"(one), "s"(ticket) : "memory");
-    };
-    // counters and claims are polled with SCALAR loads (glc: past the scalar cache, served by the
-    // XCD's L2): they wait on lgkmcnt, not on the vector-memory queue with its stores in flight
-    auto sload = [](const uint32_t *p) -> uint32_t {
-        uint32_t v;
-        asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
-        return v;
-    };
-
-    Task cur = uniform(decode(take_sync()));
-    dma_task(cur, lane0);
-    int img_of_table = -1;
-    int stores_behind_dma = 0;
-
-    while (cur.kind != END) {
-        int lane = lane0;
-        asm volatile("" : "+v"(lane));
-        if (cur.kind == NOP) {   // nothing in flight for it
-            cur = uniform(decode(take_sync()));
-            dma_task(cur, lane);
-            stores_behind_dma = 0;
-            continue;
-        }
-        const int img = cur.img;
-        if (img != img_of_table) {
-            const int qk = lane & 7, qh = lane >> 3;
-            sqw[wave][0][lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi + zigzag_of(qk, qh)]);
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                sqw[wave][1 + pl][lane] = modulate_entry(qk, qh, 0.125f,
-                    a.quanta[img * a.quanta_stride + 64 * a.cqi[pl] + zigzag_of(qk, qh)]);
-            img_of_table = img;
-        }
-        if (stores_behind_dma == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t tv = 0;
-        take_async(tv);                     // the next task's ticket: VM operation no. 1 of this task
-
-        uint32_t w[32];
-        {
-            const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
-            const int sw = (lane >> 1) & 7;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint4 v = cw[i ^ sw];
-                w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-            }
-        }
-
-        if (cur.kind == CHROMA) {
-            // ---- 64 blocks of one chroma plane -> uint8 samples (k_chroma_idct's work) ----
-            const int pl = cur.idx >= oa.cu ? 1 : 0;
-            const int bx = (cur.idx - pl * oa.cu) * 64 + lane;
-            float g[64];
-            idct_block(w, sqw[wave][1 + pl], 128.5f, g);
-            // blocks past the plane's last column go to a dump area: all 8 stores are always issued
-            // (the vmcnt arithmetic below counts them)
-            uint8_t *dst = 8 * bx < a.pw_c
-                ? const_cast<uint8_t *>(pl ? a.cr : a.cb) + img * a.c_stride + (size_t)(8 * cur.row) * a.pw_c + 8 * bx
-                : reinterpret_cast<uint8_t *>(oa.ctl + oa.dump_dword) + 8 * lane;
-            const size_t dpitch = 8 * bx < a.pw_c ? (size_t)a.pw_c : 512;
-#pragma unroll
-            for (int y = 0; y < 8; ++y) {
-                uint32_t lo = 0, hi = 0;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    lo = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + x]), x, lo);
-                    hi = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 + x]), x, hi);
-                }
-                *reinterpret_cast<uint2 *>(dst + (size_t)y * dpitch) = make_uint2(lo, hi);
-            }
-            // 8 stores are younger than the ticket atomic: <= 8 outstanding => the ticket is here
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(tv) :: "memory");
-            const Task nxt = uniform(decode(__builtin_amdgcn_readfirstlane(tv)));
-            dma_task(nxt, lane);
-            // the samples are in this XCD's L2 once the stores are acknowledged (the 8 transfers of
-            // the next task are younger than they are); then publish
-            if (nxt.kind == LUMA || nxt.kind == CHROMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_fetch_add(cnt_base + cur.slice * (oa.slice_rows + 2) + (cur.row - (cur.lo - 1)), 1u,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            stores_behind_dma = 0;
-            cur = nxt;
-            continue;
-        }
-
-        // ---- luma strip (k_luma_fused's strip body for 4:2:0) ----
-        const int lbx = lane & (BX - 1), seg = (int)((unsigned)lane / BX);
-        const int syi = cur.row, sxi = cur.idx;
-        float *sq = sqw[wave][0];
-        // the three chroma block rows under / around the strip must be complete
-        {
-            const uint32_t *cnt = cnt_base + cur.slice * (oa.slice_rows + 2) - (cur.lo - 1);
-            const int c0 = max(syi - 1, 0), c2 = min(syi + 1, oa.rows - 1);
-            int spins = 0;
-#if defined(JA_X_1P_NOCHROMA) || defined(JA_X_1P_NOPOLL)
-            if (false)
-#endif
-            while (sload(cnt + c0) < (uint32_t)nC || sload(cnt + syi) < (uint32_t)nC || sload(cnt + c2) < (uint32_t)nC) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > kSpinLimit) { if (lane == 0) *err = 2; break; }
-            }
-        }
-        const int cx0 = sxi * CW, cy0 = syi * CR;
-        const int pwd = a.pw_c >> 2;
-        {
-            const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + lane, 0), pwd - 1);
-            if (lane < PITCH) {
-#pragma unroll
-                for (int vr = 0; vr < 2 * ROWS; ++vr) {
-                    const int pl = vr >= ROWS ? 1 : 0;
-                    const int gy = min(max(cy0 - HY + vr - pl * ROWS, 0), a.ph_c - 1);
-                    const uint64_t rowbase = reinterpret_cast<uint64_t>((pl ? a.cr : a.cb) + img * a.c_stride) +
-                                             (uint64_t)((uint32_t)gy * (uint32_t)a.pw_c);
-                    lds_dma4_s_sc1(rowbase, coff, sc_lds + 4 * PITCH * vr);
-                }
-            }
-        }
-        float yv[64];
-        idct_block(w, sq, 128.5f, yv);
-#pragma unroll
-        for (int i = 0; i < 64; ++i) yv[i] = floorf(__builtin_amdgcn_fmed3f(yv[i], 0.0f, 255.0f));
-#pragma unroll
-        for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(yv[i]));
-        __builtin_amdgcn_sched_barrier(0);
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        {
-            const int first_bad = pwd - (cx0 - HX) / 4;
-            if (sxi == 0 || first_bad < PITCH) {
-                if (lane < 2 * ROWS) {
-                    uint32_t *row = sc + lane * PITCH;
-                    if (sxi == 0) row[0] = (row[0] & 0xffu) * 0x01010101u;
-                    for (int c = max(first_bad, 0); c < PITCH; ++c) row[c] = (row[c] >> 24) * 0x01010101u;
-                }
-            }
-        }
-        // vmcnt(0) above: the ticket (older than the chroma rows) is here too
-        asm volatile("" : "+v"(tv));
-        const Task nxt = uniform(decode(__builtin_amdgcn_readfirstlane(tv)));
-        dma_task(nxt, lane);
-        __builtin_amdgcn_sched_barrier(0);
-
-        constexpr float inv = 1.0f / 16.0f;
-        constexpr float bias = MODE == 1 ? -127.5f : 0.5f;
-        auto hrow = [&](int pl, int j, float (&o)[8]) {
-            const uint32_t *row = sc + pl * PLANE + (seg * (8 / SY) + j) * PITCH;
-            const uint32_t d0 = row[lbx], d1 = row[lbx + 1], d2 = row[lbx + 2];
-            const float p[6] = {ubyte<3>(d0), ubyte<0>(d1), ubyte<1>(d1), ubyte<2>(d1), ubyte<3>(d1), ubyte<0>(d2)};
-            lerp_row_2x(p, o);
-        };
-        auto finish = [&](float v) -> float { return floorf(__builtin_fmaf(v, inv, bias)); };
-        float hw[2][3][8];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) { hrow(pl, 0, hw[pl][0]); hrow(pl, 1, hw[pl][1]); }
-
-        const int tile_px = min(BX * 8, a.W - BX * 8 * sxi);
-        const int nb = 3 * tile_px;
-        const uint32_t pitch = 3u * a.W;
-        uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(16 * syi) * a.W + BX * 8 * sxi) * 3;
-        const int sg0 = lane >= 48 ? 1 : 0, j0 = lane - 48 * sg0, j1 = 16 + lane;
-        const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = 8u * pitch + 16u * j1;
-        const bool full = 16 * syi + 16 <= a.H && tile_px == BX * 8;
-        const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
-        stores_behind_dma = full ? 16 : 0;
-
-#pragma unroll
-        for (int y = 0; y < 8; ++y) {
-            if ((y & 1) == 0) __builtin_amdgcn_sched_barrier(0);
-            float cv[2][8];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                if ((y & 1) == 1) hrow(pl, (y >> 1) + 2, hw[pl][2]);
-#pragma unroll
-                for (int x = 0; x < 8; ++x) cv[pl][x] = finish(w31(hw[pl][1][x], hw[pl][(y & 1) ? 2 : 0][x]));
-                if ((y & 1) == 1) {
-#pragma unroll
-                    for (int x = 0; x < 8; ++x) { hw[pl][0][x] = hw[pl][1][x]; hw[pl][1][x] = hw[pl][2][x]; }
-                }
-            }
-            uint32_t d[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const float yy = yv[8 * y + x];
-                float c0, c1, c2;
-                if constexpr (MODE == 1) {   // jpeg.swift:441-453; see k_luma_fused for the rounding argument
-                    const float pb = cv[0][x], pr = cv[1][x];
-                    const float yb = yy + kTruncBias;
-                    c0 = __builtin_fmaf(1.40200f, pr, yb);
-                    c1 = floorf(__builtin_fmaf(-0.71414f, pr, __builtin_fmaf(-0.34414f, pb, yy)));
-                    c2 = __builtin_fmaf(1.77200f, pb, yb);
-                } else {
-                    c0 = yy; c1 = cv[0][x]; c2 = cv[1][x];
-                }
-                d[(3 * x + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c0, (3 * x + 0) & 3, d[(3 * x + 0) >> 2]);
-                d[(3 * x + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c1, (3 * x + 1) & 3, d[(3 * x + 1) >> 2]);
-                d[(3 * x + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c2, (3 * x + 2) & 3, d[(3 * x + 2) >> 2]);
-            }
-            uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
-            sw[0] = make_uint2(d[0], d[1]);
-            sw[1] = make_uint2(d[2], d[3]);
-            sw[2] = make_uint2(d[4], d[5]);
-            uint8_t *rowp = strip_out + (size_t)y * pitch;
-            const uint4 v0 = *reinterpret_cast<const uint4 *>(stage_w + 4 * lane);
-            const uint4 v1 = *reinterpret_cast<const uint4 *>(stage_w + 4 * (64 + (lane & 31)));
-            if (full) {
-                store_nt16(rowp + voff0, v0);
-                if (lane < 32) store_nt16(rowp + voff1, v1);
-            } else {
-                if (col0 && 16 * syi + 8 * sg0 + y < a.H) store_nt16(rowp + voff0, v0);
-                if (col1 && 16 * syi + 8 + y < a.H) store_nt16(rowp + voff1, v1);
-            }
-        }
-        cur = nxt;
-    }
-}
-
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
 
 // Persistent grid = what is resident at once: workgroups per CU (LDS- and VGPR-bound, differs per
@@ -1064,38 +645,6 @@ extern "C" int jpeg_amd_debug_phase_cycles(unsigned long long *h_out, size_t n)
 }
 #endif
 
-// One-launch plan for 4:2:0 (k_decode_onepass); enabled == false: the two-launch path.
-struct OnePassPlan {
-    bool enabled;
-    int rows, slice_rows, slices_per_image, nslices, cu, lead, max_claims;
-    size_t ctl_dwords;
-};
-static OnePassPlan onepass_plan(const jpeg_amd_layout &L, int n_images)
-{
-    OnePassPlan p{};
-#ifndef JA_X_ONEPASS   // prototype, off: measured slower than the two launches
-    return p;
-#endif
-    if (L.nplanes != 3 || L.scale_x != 2 || L.scale_y != 2 || n_images < 1) return p;
-    const int ux = L.units_x[0], uy = L.units_y[0];
-    if (strip_width(ux, uy, 2, 2) != 32) return p;
-    p.rows = (uy + 1) / 2;
-    if (p.rows != L.units_y[1]) return p;   // chroma block rows == luma strip rows (layout-derived geometry)
-    // slices of about 32 strip rows; the chroma rows run `lead` rows ahead of the luma rows
-    p.slices_per_image = (p.rows + 31) / 32;
-    p.slice_rows = (p.rows + p.slices_per_image - 1) / p.slices_per_image;
-    p.nslices = p.slices_per_image * n_images;
-    p.lead = 16;
-    p.cu = (L.units_x[1] + 63) / 64;
-    p.max_claims = p.nslices + 2;
-    // worth it only when there is enough work to keep the ticket streams of 8 XCDs busy
-    if ((long)p.nslices * p.slice_rows < 256 || p.slice_rows < 8) return p;
-    p.ctl_dwords = (size_t)kCtlMine + (size_t)16 * p.max_claims + (size_t)p.nslices * (p.slice_rows + 2);
-    p.ctl_dwords = (p.ctl_dwords + 63) & ~(size_t)63;   // the dump area (1024 dwords) follows, 256-byte aligned
-    p.enabled = true;
-    return p;
-}
-
 bool fused_decode_supported(const jpeg_amd_layout &L, bool cosited)
 {
     if (L.precision != 8) return false;
@@ -1117,8 +666,7 @@ size_t fused_decode_scratch_bytes(const jpeg_amd_layout &L, int n_images)
 {
     if (L.nplanes == 1 || (L.scale_x == 1 && L.scale_y == 1)) return 0;   // grey, 4:4:4: no intermediate
     const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
-    const OnePassPlan op = onepass_plan(L, n_images);
-    return 2 * ((plane * n_images + 255) & ~(size_t)255) + (op.enabled ? 4 * op.ctl_dwords + 4096 + 256 : 0);
+    return 2 * ((plane * n_images + 255) & ~(size_t)255);
 }
 
 hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L,
@@ -1146,42 +694,6 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
             ca.qi[i] = L.qi[1 + i];
         }
         ca.out_stride = plane;
-        const OnePassPlan op = onepass_plan(L, n_images);
-        const bool fast_out = (L.width & 15) == 0 && (pixel_stride & 15) == 0 &&
-                              (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-        if (op.enabled && fast_out) {
-            OnePassArgs oa{};
-            LumaArgs &l = oa.l;
-            for (int i = 0; i < 2; ++i) {
-                l.ccoef[i] = ca.coef[i]; l.ccoef_stride[i] = ca.coef_stride[i]; l.cqi[i] = ca.qi[i];
-            }
-            l.cb = ca.out[0]; l.cr = ca.out[1]; l.c_stride = plane;
-            l.pw_c = 8 * L.units_x[1]; l.ph_c = 8 * L.units_y[1];
-            l.coef = static_cast<const int16_t *>(coef.ptr[0]); l.coef_stride = coef.stride[0];
-            l.quanta = q.d_quanta; l.quanta_stride = q.image_stride; l.qi = L.qi[0];
-            l.ux = L.units_x[0]; l.uy = L.units_y[0]; l.W = L.width; l.H = L.height;
-            l.out = d_pixels; l.out_stride = pixel_stride;
-            l.tiles_x = (l.ux + 31) / 32;
-            oa.rows = op.rows; oa.slice_rows = op.slice_rows; oa.slices_per_image = op.slices_per_image;
-            oa.nslices = op.nslices; oa.cu = op.cu; oa.lead = op.lead; oa.max_claims = op.max_claims;
-            oa.dump_dword = (int)op.ctl_dwords;
-            oa.ctl = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(scratch) + 2 * half);
-            hipError_t e = hipMemsetAsync(oa.ctl, 0, 4 * op.ctl_dwords, stream);
-            if (e != hipSuccess) return e;
-            static int cap[2] = {0, 0};
-            const int mode = rgb ? 1 : 0;
-            if (cap[mode] == 0) {
-                int per_cu = 0, dev = 0, cus = 0;
-                const void *fn = rgb ? reinterpret_cast<const void *>(k_decode_onepass<1>) : reinterpret_cast<const void *>(k_decode_onepass<0>);
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-                if (hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-                cap[mode] = per_cu * cus;
-            }
-            if (rgb) hipLaunchKernelGGL(k_decode_onepass<1>, dim3(cap[mode]), dim3(kThreads), 0, stream, oa);
-            else hipLaunchKernelGGL(k_decode_onepass<0>, dim3(cap[mode]), dim3(kThreads), 0, stream, oa);
-            return hipGetLastError();
-        }
         ca.quanta = q.d_quanta; ca.quanta_stride = q.image_stride;
         ca.ux = L.units_x[1]; ca.nblocks = L.units_x[1] * L.units_y[1];
 #ifdef JA_X_SKIPK1

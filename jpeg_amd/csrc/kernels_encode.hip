@@ -119,12 +119,13 @@ __device__ __forceinline__ void fdct_quantise(const float (&g)[64], const float 
 // third of its time on.  Instead the blocks go through a wave-private 8 KiB LDS buffer (chunk c
 // of lane L at slot c ^ ((L >> 1) & 7), conflict-free for the stride-128-byte writes) and come
 // back lane-linear: instruction i writes the complete lines of blocks 8i .. 8i + 7, each lane one
-// 16-byte chunk, with the `nt` hint (streaming output).  `offset` = byte offset of the lane's
-// block from `plane` (wave-uniform), or ~0u for a block outside the plane; the producer's offset
-// reaches the storing lane through ds_bpermute.  LDS operations of one wave execute in order, so
+// 16-byte chunk, with the `nt` hint (streaming output).  `block` = index of the lane's block in
+// `plane` (wave-uniform base; a plane of a 65535 x 65535 image exceeds 4 GiB, so the byte offset
+// is formed in 64 bits by the storing lane), or ~0u for a block outside the plane; the producer's
+// index reaches the storing lane through ds_bpermute.  LDS operations of one wave execute in order, so
 // no barrier is needed; all 64 lanes must call this together.
 __device__ __forceinline__ void wave_store_blocks(const uint32_t (&w)[32], uint32_t *stage, int lane,
-                                                  int16_t *plane, uint32_t offset)
+                                                  int16_t *plane, uint32_t block)
 {
     uint4 *mine = reinterpret_cast<uint4 *>(stage) + 8 * lane;
     const int sw = (lane >> 1) & 7;
@@ -135,13 +136,13 @@ __device__ __forceinline__ void wave_store_blocks(const uint32_t (&w)[32], uint3
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int producer = 8 * i + (lane >> 3);
-        const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * producer, (int)offset);
+        const uint32_t blk = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * producer, (int)block);
         const int c = (lane & 7) ^ ((producer >> 1) & 7);
         const uint4 v = all[64 * i + lane];
 #ifdef JA_X_ENC_NOSTORE
         if (plane == nullptr)
 #endif
-        if (off != ~0u) store_nt16(base + off + 16 * c, v);
+        if (blk != ~0u) store_nt16(base + ((size_t)blk << 7) + 16 * c, v);
     }
 }
 
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
             // 2 * CBX * CBY and CBX * CBY are multiples of 64: the loop is wave-uniform and a wave
             // never straddles the two planes
             const int plu = __builtin_amdgcn_readfirstlane(pl);
-            const uint32_t off = (bx < a.ux[1 + plu] && by < a.uy[1 + plu]) ? 128u * (uint32_t)(by * a.ux[1 + plu] + bx) : ~0u;
+            const uint32_t off = (bx < a.ux[1 + plu] && by < a.uy[1 + plu]) ? (uint32_t)(by * a.ux[1 + plu] + bx) : ~0u;
             wave_store_blocks(w, stage, lane, a.coef[1 + plu] + img * a.coef_stride[1 + plu], off);
         }
     };
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
         {
             uint32_t w[32];
             fdct_quantise(yv, sq[0], sr[0], w);
-            const uint32_t off = (bx < a.ux[0] && by < a.uy[0]) ? 128u * (uint32_t)(by * a.ux[0] + bx) : ~0u;
+            const uint32_t off = (bx < a.ux[0] && by < a.uy[0]) ? (uint32_t)(by * a.ux[0] + bx) : ~0u;
             wave_store_blocks(w, stage, lane, a.coef[0] + img * a.coef_stride[0], off);
         }
         if constexpr (CHROMA && INTHREAD) {
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
                 }
                 uint32_t w[32];
                 fdct_quantise(g, sq[1 + pl], sr[1 + pl], w);
-                const uint32_t off = (bx < a.ux[1 + pl] && by < a.uy[1 + pl]) ? 128u * (uint32_t)(by * a.ux[1 + pl] + bx) : ~0u;
+                const uint32_t off = (bx < a.ux[1 + pl] && by < a.uy[1 + pl]) ? (uint32_t)(by * a.ux[1 + pl] + bx) : ~0u;
                 wave_store_blocks(w, stage, lane, a.coef[1 + pl] + img * a.coef_stride[1 + pl], off);
             }
         }

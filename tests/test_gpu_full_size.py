@@ -143,3 +143,62 @@ def test_one_image_in_bands_across_ranks_is_bit_identical():
         y0, y1 = plan["rows"]
         rows.append(px[plan["skip"]:plan["skip"] + (y1 - y0)])
     assert torch.equal(torch.cat(rows), whole)
+
+
+def test_planes_beyond_4GiB_are_addressed_in_64_bits(env):
+    """A 65520 x 33024 4:2:0 image: luma coefficient plane 4.3 GB, RGB 6.5 GB -- byte offsets no
+    longer fit 32 bits (the frame header allows 65535 x 65535).  No oracle run at this size: bands
+    of whole MCU rows decoded / encoded as small sub-images through the SAME (oracle-checked)
+    kernels, from row slices of the resident buffers, must equal the whole-image result."""
+    e = env
+    torch, _lib, lib, ctx = e["torch"], e["_lib"], e["lib"], e["ctx"]
+    dev = ctx.torch_device
+    W, H = 65520, 33024
+    units = e["layout"].units((W, H))
+    assert 128 * units[0][0] * units[0][1] > 1 << 32 and 3 * W * H > 1 << 32
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    planes = []
+    for ux, uy in units:
+        p = torch.randint(-40, 41, (uy * ux, 64), dtype=torch.int16, device=dev, generator=g)
+        p[:, 10:] = 0
+        p[:, 0] *= 8
+        planes.append(p.view(-1))
+    n_mcu = H // 16
+
+    def decode(m0, m1, out):
+        size = (W, (m1 - m0) * 16)
+        L = e["layout"].c_layout(size, e["layout"].units(size), [0, 1, 1])
+        ptrs = [p.data_ptr() + 2 * 64 * ux * (m0 * f) for p, (ux, _), f in zip(planes, units, (2, 1, 1))]
+        st = lib.jpeg_amd_decode_batch(ctx.handle, C.byref(L), 1, _lib.ptr_array(ptrs), _lib.size_array([0, 0, 0]),
+                                       e["d_q"].data_ptr(), 0, 2, 0, _lib.COLOR_RGB8, out.data_ptr(), 0)
+        assert st == 0
+
+    rgb = torch.empty(3 * W * H, dtype=torch.uint8, device=dev)
+    decode(0, n_mcu, rgb)
+    rows = rgb.view(H, 3 * W)
+    straddle = (1 << 32) // (3 * W) // 16          # the MCU row whose pixels cross the 4 GiB offset
+    for m0, m1, top, bottom in [(0, 6, 0, 1), (straddle - 4, straddle + 4, 1, 1), (n_mcu - 6, n_mcu, 1, 0)]:
+        band = torch.empty(3 * W * (m1 - m0) * 16, dtype=torch.uint8, device=dev)
+        decode(m0, m1, band)
+        band = band.view(-1, 3 * W)
+        # the sub-image replicates chroma at its own top / bottom edge: skip the halo MCU row there
+        a, b = 16 * top, band.shape[0] - 16 * bottom
+        assert torch.equal(band[a:b], rows[16 * m0 + a:16 * m0 + b]), (m0, m1)
+
+    def encode(m0, m1, coefs):
+        size = (W, (m1 - m0) * 16)
+        L = e["layout"].c_layout(size, e["layout"].units(size), [0, 1, 1])
+        st = lib.jpeg_amd_encode_batch(ctx.handle, C.byref(L), 1, rgb.data_ptr() + 3 * W * 16 * m0, 0, _lib.COLOR_RGB8,
+                                       e["d_q"].data_ptr(), 0, 2, _lib.ptr_array([c.data_ptr() for c in coefs]),
+                                       _lib.size_array([0, 0, 0]))
+        assert st == 0
+
+    del planes
+    whole = [torch.empty(64 * ux * uy, dtype=torch.int16, device=dev) for ux, uy in units]
+    encode(0, n_mcu, whole)
+    last_luma = (1 << 32) // (128 * units[0][0]) // 2   # the MCU row whose luma blocks cross 4 GiB
+    for m0, m1 in [(0, 4), (last_luma - 2, last_luma + 2), (n_mcu - 4, n_mcu)]:
+        part = [torch.empty(64 * ux * (m1 - m0) * f, dtype=torch.int16, device=dev) for (ux, _), f in zip(units, (2, 1, 1))]
+        encode(m0, m1, part)
+        for c, w, (ux, _), f in zip(part, whole, units, (2, 1, 1)):
+            assert torch.equal(c, w[64 * ux * m0 * f:64 * ux * m1 * f]), (m0, m1)

@@ -274,6 +274,16 @@ def main():
         if world == 1 and not args.no_extras:
             result["extra"] = extras(J, ctx, d_quanta, q_np, sync, args)
             encode_case = result["extra"].pop("_c4_host_case", None)
+            # what the vendor's device-to-device memcpy moves on THIS box (read + written bytes per
+            # second), measured just now: the practical ceiling of a 1 : 1 read / write stream
+            d2d = result["extra"].pop("_d2d_copy_GBps", None)
+            if d2d:
+                rf = result["roofline"]
+                rf["d2d_memcpy_live_GBps"] = d2d
+                rf["achieved_over_d2d_memcpy"] = round(rf["achieved"] / d2d, 4)
+                if rf["traffic"]:
+                    rf["traffic_rate_over_d2d_memcpy"] = round(
+                        rf["traffic"] / (rf["gpu_ms_per_step_hip_events"] * 1e-3) / 1e9 / d2d, 4)
         if world == 1 and not args.no_cpu:
             planes_h, pixels_h = wl.host_case(0)
             cb = cpu_baseline(J, q_np, args.cpu_seconds, (planes_h, pixels_h, wl.size), encode_case)
@@ -297,6 +307,17 @@ def extras(J, ctx, d_quanta, q_np, sync, args):
     out = {}
     dev = ctx.torch_device
     lib = _lib.lib()
+
+    # live device-to-device copy rate (1 GiB, best of 5)
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(6):
+        e0.record(); dst.copy_(src); e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    out["_d2d_copy_GBps"] = round(2.0 * src.numel() / (best * 1e-3) / 1e9, 1)
+    del src, dst
 
     # C2-shaped: IDCT + dequant only, 2^22 blocks (bandwidth figure; the 100k-block
     # bit-exactness check is tests/test_gpu_parity.py::test_c2_100k_blocks_idct)

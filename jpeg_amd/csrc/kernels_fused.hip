@@ -3,8 +3,8 @@
 // Replaces idct() -> interleaved(cosite: false) -> unpack(as:) (decode.swift:4154, 4182,
 // 4294) for ycc8 images whose luma has the full sampling factor and whose chroma planes are
 // subsampled 1x or 2x per axis (4:4:4, 4:2:2, 4:4:0, 4:2:0), and for y8 images, without
-// materialising Planar / Rectangular in HBM.  Two launches (one for y8 and for 4:4:4, where
-// every work-item transforms the Cb and Cr blocks under its luma block itself):
+// materialising Planar / Rectangular in HBM.  Two launches (one for y8, 4:4:4 and 4:2:2, where
+// the work-items transform the Cb and Cr blocks under their strip themselves):
 //
 //   k_chroma_idct   Cb and Cr: dequantise + IDCT, clamp, store as uint8 planes (a scratch of
 //                   0.5 B/px for 4:2:0 -- small enough to stay in L2 / Infinity Cache).
@@ -213,7 +213,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     constexpr int PLANE = (CHROMA && !INTHREAD) ? ROWS * PITCH : 1;
     constexpr int SEG_DW = BX * 6;                       // one pixel row of one block row: 24 B per block
     constexpr int CPS = SEG_DW / 4;                      // 16-byte chunks per such segment
-    constexpr int NTAB = INTHREAD ? 3 : 1;
+    // 4:2:2 (wide strips): the 16 x 2 chroma blocks per plane under a strip are exactly one block per
+    // work-item for both planes together; a second, nearly empty pass transforms the 8 neighbour
+    // blocks that supply the one-sample halo left and right.  No k_chroma_idct launch, no chroma
+    // round trip through HBM (it was 134 of 604 MB at 8192 x 8192).
+    constexpr bool IN422 = CHROMA && SX == 2 && SY == 1 && BX == 32;
+    constexpr int NTAB = (INTHREAD || IN422) ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
@@ -241,12 +246,49 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
 
     // LDS-DMA of the 64 blocks of strip s: instruction i moves 64 x 16 B; slot
     // u = 64 i + lane holds chunk (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3.
-    auto dma_strip = [&](int s, int lane, int which = 0) {   // which: 0 luma, 1 Cb, 2 Cr (4:4:4 only)
+    // which: 0 luma; 4:4:4: 1 Cb, 2 Cr; 4:2:2: 1 both chroma planes under the strip, 2 their halo blocks
+    auto dma_strip = [&](int s, int lane, int which = 0) {
         int img, syi, sxi;
         locate(s, img, syi, sxi);
         const int16_t *base = a.coef + img * a.coef_stride;
         if constexpr (INTHREAD) {
             if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
+        }
+        if constexpr (IN422) {
+            const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
+            if (which == 1) {   // block b of the buffer: plane b >> 5, row (b >> 4) & 1, column b & 15
+                if (16 * sxi + 16 <= uxc && 2 * syi + 2 <= uyc) {
+                    const uint32_t l3 = lane >> 3;
+                    const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int16_t *cbase = a.ccoef[i >> 2] + img * a.ccoef_stride[i >> 2];
+                        const uint32_t blk0 = (uint32_t)(2 * syi + ((i >> 1) & 1)) * uxc + 16 * sxi + 8 * (i & 1);
+                        const uint64_t sb = reinterpret_cast<uint64_t>(cbase) + ((uint64_t)blk0 << 7);
+                        lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+                    }
+                    return;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int16_t *cbase = a.ccoef[i >> 2] + img * a.ccoef_stride[i >> 2];
+                    const int b = 8 * i + (lane >> 3);
+                    const int bx = 16 * sxi + (b & 15), by = 2 * syi + ((b >> 4) & 1);
+                    const uint32_t blk = (bx < uxc && by < uyc) ? (uint32_t)by * uxc + bx : 0u;
+                    const int c = (lane & 7) ^ ((b >> 1) & 7);
+                    lds_dma16(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+                }
+                return;
+            }
+            if (which == 2) {   // block b = 0..7: plane b >> 2, side (b >> 1) & 1 (0 left, 1 right), row b & 1
+                const int b = lane >> 3;
+                const int16_t *cbase = a.ccoef[b >> 2] + img * a.ccoef_stride[b >> 2];
+                const int bx = ((b >> 1) & 1) ? 16 * sxi + 16 : 16 * sxi - 1, by = 2 * syi + (b & 1);
+                const uint32_t blk = (bx >= 0 && bx < uxc && by < uyc) ? (uint32_t)by * uxc + bx : 0u;
+                const int c = (lane & 7) ^ ((b >> 1) & 7);
+                lds_dma16(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds);
+                return;
+            }
         }
         if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {
             // interior strip (wave-uniform test): the block index is scalar, only the lane's
@@ -276,7 +318,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     const int nwaves = gridDim.x * NW;
     int s = blockIdx.x * NW + wave;
     if (s >= a.total_tiles) return;
-    dma_strip(s, lane0, INTHREAD ? 1 : 0);
+    dma_strip(s, lane0, (INTHREAD || IN422) ? 1 : 0);
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
 #ifdef JA_PHASE_PROFILE
@@ -297,7 +339,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         if (img != img_of_table) {
             const int qk = lane & 7, qh = lane >> 3;
             sq[lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi + zigzag_of(qk, qh)]);
-            if constexpr (INTHREAD) {
+            if constexpr (INTHREAD || IN422) {
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     sqw[wave][1 + pl][lane] = modulate_entry(qk, qh, 0.125f,
@@ -351,13 +393,71 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             }
         }
 
+        if constexpr (IN422) {
+            // pass 1: the strip's own chroma blocks (lane: plane, block row, block column)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_strip(s, lane, 2);
+            {
+                const int pl = lane >> 5, r = (lane >> 4) & 1, c = lane & 15;
+                float g[64];
+                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                uint32_t *dst = sc + pl * PLANE + 8 * r * PITCH + 1 + 2 * c;
+#pragma unroll
+                for (int y = 0; y < 8; ++y)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 * d + i]), i, v);
+                        dst[y * PITCH + d] = v;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_block();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_strip(s, lane, 0);
+            // pass 2 (8 work-items): the neighbour blocks' edge columns -> the tile's halo dwords
+            {
+                const int pl = (lane >> 2) & 1, side = (lane >> 1) & 1, r = lane & 1;
+                float g[64];
+                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                const bool exists = side ? 16 * sxi + 16 < (a.pw_c >> 3) : sxi > 0;
+                if (lane < 8 && exists) {
+                    uint32_t *dst = sc + pl * PLANE + 8 * r * PITCH + (side ? PITCH - 1 : 0);
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) {
+                        const uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(floorf(side ? g[8 * y] : g[8 * y + 7]), 0, 0u);
+                        dst[y * PITCH] = v * 0x01010101u;
+                    }
+                }
+            }
+            // plane edges: the reference clamps the sample index to the padded plane (decode.swift:4245)
+            {
+                const int first_bad = (a.pw_c >> 2) - (sxi * CW - HX) / 4;   // first tile dword past the plane
+                if (sxi == 0 || first_bad < PITCH) {
+                    if (lane < 2 * ROWS) {
+                        uint32_t *row = sc + lane * PITCH;
+                        if (sxi == 0) row[0] = (row[1] & 0xffu) * 0x01010101u;
+                        if (first_bad < PITCH) {
+                            const uint32_t last = (row[first_bad - 1] >> 24) * 0x01010101u;
+                            for (int c = first_bad; c < PITCH; ++c) row[c] = last;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_block();
+        }
+
         // ---- chroma samples under the strip (+ halo): one LDS-DMA per row straight into this
         //      wave's LDS tile (lane = dword column); they land during the IDCT.  Row index
         //      clamped by the scalar unit, column index clamped per lane to the padded plane;
         //      the replication a clamped COLUMN needs is patched in LDS on edge strips only. ----
         const int cx0 = sxi * CW, cy0 = syi * CR;
         const int pwd = a.pw_c >> 2;
-        if constexpr (CHROMA && !INTHREAD) {
+        if constexpr (CHROMA && !INTHREAD && !IN422) {
             // rows of a narrow tile are packed RPI to a transfer (the LDS image is lane-linear and the
             // tile rows are contiguous): 12 transfers instead of 36 for a 16 x 4 strip of 4:2:0
             constexpr int RPI = (ROWS % (64 / PITCH) == 0) ? 64 / PITCH : 1;
@@ -410,7 +510,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         JA_PHASE(2)
 
         // ---- the chroma rows have landed (they are the only VM operations in flight) ----
-        if constexpr (CHROMA && !INTHREAD) {
+        if constexpr (CHROMA && !INTHREAD && !IN422) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int first_bad = pwd - (cx0 - HX) / 4;          // first column past the plane
             if ((HX > 0 && sxi == 0) || first_bad < PITCH) {     // wave-uniform: edge strips only
@@ -424,7 +524,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         }
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
-        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, INTHREAD ? 1 : 0);
+        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, (INTHREAD || IN422) ? 1 : 0);
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(3)
@@ -628,10 +728,10 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
 // tiles of a 16 x 4 strip would need 64 row transfers.
 inline int strip_width(int ux, int uy, int sx, int sy)
 {
+    if (sx != sy) return 32;   // (the 4:2:2 in-thread chroma passes are written for the wide strip)
 #ifdef JA_X_FORCE_BX
     return JA_X_FORCE_BX;
 #endif
-    if (sx != sy) return 32;
     const long wide = (long)((ux + 31) / 32) * ((uy + 1) / 2), narrow = (long)((ux + 15) / 16) * ((uy + 3) / 4);
     return narrow < wide ? 16 : 32;
 }
@@ -664,7 +764,7 @@ bool fused_decode_supported(const jpeg_amd_layout &L, bool cosited)
 
 size_t fused_decode_scratch_bytes(const jpeg_amd_layout &L, int n_images)
 {
-    if (L.nplanes == 1 || (L.scale_x == 1 && L.scale_y == 1)) return 0;   // grey, 4:4:4: no intermediate
+    if (L.nplanes == 1 || L.scale_y == 1) return 0;   // grey, 4:4:4, 4:2:2: no intermediate
     const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
     return 2 * ((plane * n_images + 255) & ~(size_t)255);
 }
@@ -675,7 +775,8 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
 {
     const bool chroma = L.nplanes == 3;
     // 4:4:4: k_luma_fused transforms all three planes itself (no intermediate, no first launch)
-    const bool inthread = chroma && L.scale_x == 1 && L.scale_y == 1;
+    // 4:2:2 likewise (the chroma blocks under a strip are one per work-item; see IN422)
+    const bool inthread = chroma && L.scale_y == 1;
     LumaArgs la{};
     if (inthread) {
         for (int i = 0; i < 2; ++i) {
@@ -683,6 +784,7 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
             la.ccoef_stride[i] = coef.stride[1 + i];
             la.cqi[i] = L.qi[1 + i];
         }
+        la.pw_c = 8 * L.units_x[1]; la.ph_c = 8 * L.units_y[1];
     } else if (chroma) {
         const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
         const size_t half = (plane * n_images + 255) & ~(size_t)255;

@@ -189,6 +189,26 @@ __device__ __forceinline__ void idct_pass2_row(const float (&f)[64], int y, floa
     idct8<true>(r, level, g);
 }
 
+// ONE output row of idct_block: row 0 (last == false) or row 7 (last == true; may differ per lane).
+// Same operations in the same order for the values that are kept; what the other rows would have
+// needed is never computed (the unused butterfly outputs are dead code).
+template <typename QPtr>
+__device__ __forceinline__ void idct_block_edge_row(const uint32_t (&w)[32], QPtr q, float level, bool last,
+                                                    float (&g)[8])
+{
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float h[8], res[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh)
+            h[hh] = q[8 * hh + k] * coef_as_float(w, zigzag_of(k, hh));
+        idct8<false>(h, 0.0f, res);
+        t[k] = last ? res[7] : res[0];
+    }
+    idct8<true>(t, level, g);
+}
+
 // Planar.Plane.load + fdct8x8 -- encode.swift:80-99, 191-196.
 // g[8*y + x]: samples already min(limit, Float(sample)); out H[8*h + k] before quantise.
 __device__ __forceinline__ void fdct_block(const float (&g)[64], float level, float (&H)[64])

@@ -25,7 +25,9 @@
 // Development switches (never defined in the product build; tools/build_exp.sh makes A/B builds,
 // DESIGN.md section 6 quotes the measurements): JA_PHASE_PROFILE (per-phase cycle counters,
 // tools/phase_profile.py), JA_X_NOIDCT / JA_X_NOSTORE (the kernel without its arithmetic / without
-// its stores), JA_X_SKIPK1 / JA_X_SKIPK2 (one launch of the pair only, tools/probe_overlap.py).
+// its stores), JA_X_SKIPK1 / JA_X_SKIPK2 (one launch of the pair only, tools/probe_overlap.py),
+// JA_X_NO_IN420 / JA_X_FORCE_IN420 (4:2:0 chroma in the strip walk never / whenever the strips are wide),
+// JA_X_IN420_NT (its neighbour fetches with the `nt` hint: 8 % slower, they are re-used out of L2).
 #pragma clang fp contract(off)
 
 #include "dct.hpp"
@@ -176,6 +178,21 @@ __device__ __forceinline__ void lds_dma16_s(uint64_t sbase, uint32_t voff, uint3
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
 }
+// The same two without the `nt` hint: for coefficients that neighbouring strips fetch again soon
+// (the chroma blocks around a 4:2:0 strip) and should therefore stay in L2.
+#ifdef JA_X_IN420_NT
+#define JA_KEEP_HINT " nt"
+#else
+#define JA_KEEP_HINT ""
+#endif
+__device__ __forceinline__ void lds_dma16_keep(const void *g, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" JA_KEEP_HINT ::"v"(g), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_s_keep(uint64_t sbase, uint32_t voff, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" JA_KEEP_HINT ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
 // 4 bytes per lane: lane l's dword lands at LDS byte address lds + 4 l.
 __device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32_t lds)
 {
@@ -195,7 +212,7 @@ __device__ unsigned long long g_phase_cycles[4096 * 8];
 #define JA_PHASE(i)
 #endif
 
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX>
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false>
 __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
 {
     constexpr int BY = 64 / BX;                          // block rows per strip
@@ -218,7 +235,20 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     // blocks that supply the one-sample halo left and right.  No k_chroma_idct launch, no chroma
     // round trip through HBM (it was 134 of 604 MB at 8192 x 8192).
     constexpr bool IN422 = CHROMA && SX == 2 && SY == 1 && BX == 32;
-    constexpr int NTAB = (INTHREAD || IN422) ? 3 : 1;
+    // 4:2:0 (wide strips), same idea with a two-dimensional halo: pass 1 transforms the 16 chroma
+    // blocks per plane under the strip and the 6 blocks per plane left and right of the three block
+    // rows involved (edge column / corner sample: 44 work-items); pass 2 the 16 blocks above and the
+    // 16 below per plane, of which only the last / first sample row is wanted -- about a third of a
+    // block's arithmetic (idct_block_edge_row).  108 blocks where k_chroma_idct transforms 32 per
+    // strip, but no second launch and no chroma samples through HBM.  The neighbours' coefficients are fetched
+    // without `nt`: the strips above and below run at the same time on the same XCD (strip s and
+    // s + 32 are 8 workgroups apart) and find them in L2.
+    // STRIP420 selects it: it wins where the second launch is what costs (one image of up to 4096 x 4096:
+    // 27 instead of 31 us there, 12.4 instead of 14.5 at 2048 x 2048), it ties at 8192 x 8192 and loses on
+    // batches of narrower images, whose vertical neighbours run on other XCDs and miss in L2 (+ 15 %).
+    constexpr bool IN420 = STRIP420 && CHROMA && SX == 2 && SY == 2 && BX == 32;
+    constexpr bool INSTRIP = INTHREAD || IN422 || IN420;   // no k_chroma_idct in front of this kernel
+    constexpr int NTAB = INSTRIP ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
@@ -253,6 +283,54 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         const int16_t *base = a.coef + img * a.coef_stride;
         if constexpr (INTHREAD) {
             if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
+        }
+        if constexpr (IN420) {
+            const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
+            const int row_above = max(syi - 1, 0), row_below = min(syi + 1, uyc - 1);   // missing rows: fetched, not used
+            if (which == 1) {
+                // blocks 0..31: plane b >> 4, column b & 15 of the strip's own chroma row; blocks 32..43: plane
+                // (b - 32) / 6, row syi - 1 + ((b - 32) % 6 >> 1), side (b - 32) & 1 (0: column 16 sxi - 1, 1: 16 sxi + 16)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int b = 8 * i + (lane >> 3);
+                    int pl, bx, by;
+                    if (i < 4) { pl = i >> 1; bx = 16 * sxi + (b & 15); by = syi; }
+                    else {
+                        const int idx = min(b - 32, 11), j = idx % 6;
+                        pl = idx / 6; bx = (j & 1) ? 16 * sxi + 16 : 16 * sxi - 1;
+                        by = min(max(syi - 1 + (j >> 1), 0), uyc - 1);
+                    }
+                    const int16_t *cbase = a.ccoef[pl] + img * a.ccoef_stride[pl];
+                    const uint32_t blk = (bx >= 0 && bx < uxc) ? (uint32_t)by * uxc + bx : 0u;
+                    const int c = (lane & 7) ^ ((b >> 1) & 7);
+                    lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+                }
+                return;
+            }
+            if (which == 2) {   // block b: plane b >> 5, (b >> 4) & 1: 0 the row above, 1 the row below; column b & 15
+                if (16 * sxi + 16 <= uxc) {
+                    const uint32_t l3 = lane >> 3;
+                    const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int16_t *cbase = a.ccoef[i >> 2] + img * a.ccoef_stride[i >> 2];
+                        const uint32_t blk0 = (uint32_t)(((i >> 1) & 1) ? row_below : row_above) * uxc + 16 * sxi + 8 * (i & 1);
+                        const uint64_t sb = reinterpret_cast<uint64_t>(cbase) + ((uint64_t)blk0 << 7);
+                        lds_dma16_s_keep(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+                    }
+                    return;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int16_t *cbase = a.ccoef[i >> 2] + img * a.ccoef_stride[i >> 2];
+                    const int b = 8 * i + (lane >> 3);
+                    const int bx = 16 * sxi + (b & 15), by = ((b >> 4) & 1) ? row_below : row_above;
+                    const uint32_t blk = bx < uxc ? (uint32_t)by * uxc + bx : 0u;
+                    const int c = (lane & 7) ^ ((b >> 1) & 7);
+                    lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+                }
+                return;
+            }
         }
         if constexpr (IN422) {
             const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
@@ -318,7 +396,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     const int nwaves = gridDim.x * NW;
     int s = blockIdx.x * NW + wave;
     if (s >= a.total_tiles) return;
-    dma_strip(s, lane0, (INTHREAD || IN422) ? 1 : 0);
+    dma_strip(s, lane0, INSTRIP ? 1 : 0);
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
 #ifdef JA_PHASE_PROFILE
@@ -339,7 +417,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         if (img != img_of_table) {
             const int qk = lane & 7, qh = lane >> 3;
             sq[lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi + zigzag_of(qk, qh)]);
-            if constexpr (INTHREAD || IN422) {
+            if constexpr (INSTRIP) {
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     sqw[wave][1 + pl][lane] = modulate_entry(qk, qh, 0.125f,
@@ -393,6 +471,89 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
             }
         }
 
+        if constexpr (IN420) {
+            const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
+            const bool has_above = syi > 0, has_below = syi + 1 < uyc;        // wave-uniform
+            const bool has_left = sxi > 0, has_right = 16 * sxi + 16 < uxc;
+            auto pack4 = [](const float *v) -> uint32_t {
+                uint32_t d = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v[i]), i, d);
+                return d;
+            };
+            auto rep1 = [](float v) -> uint32_t { return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v), 0, 0u) * 0x01010101u; };
+            // pass 1: the strip's own chroma blocks (8 sample rows -> tile rows 1..8) and the 12 side blocks
+            // (edge column of the own row's neighbours, corner sample of the rows above / below)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_strip(s, lane, 2);
+            {
+                float g[64];
+                const int idx = min(max(lane - 32, 0), 11), j = idx % 6;
+                const int pl = lane < 32 ? lane >> 4 : idx / 6;
+                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                if (lane < 32) {
+                    uint32_t *dst = sc + pl * PLANE + 1 + 2 * (lane & 15);
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) {
+                        dst[(1 + y) * PITCH] = pack4(&g[8 * y]);
+                        dst[(1 + y) * PITCH + 1] = pack4(&g[8 * y + 4]);
+                    }
+                } else if (lane < 44) {
+                    const int rowsel = j >> 1, side = j & 1;
+                    const bool ok = (side ? has_right : has_left) && (rowsel == 0 ? has_above : rowsel == 2 ? has_below : true);
+                    if (ok) {
+                        uint32_t *dst = sc + pl * PLANE + (side ? PITCH - 1 : 0);
+                        if (rowsel == 1) {
+#pragma unroll
+                            for (int y = 0; y < 8; ++y) dst[(1 + y) * PITCH] = rep1(side ? g[8 * y] : g[8 * y + 7]);
+                        } else if (rowsel == 0) dst[0] = rep1(side ? g[56] : g[63]);
+                        else dst[9 * PITCH] = rep1(side ? g[0] : g[7]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_block();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_strip(s, lane, 0);
+            // pass 2: the blocks above (their last sample row -> tile row 0) and below (first row -> tile row 9)
+            {
+                const int pl = lane >> 5, below = (lane >> 4) & 1;
+                float r[8];
+                idct_block_edge_row(w, sqw[wave][1 + pl], 128.5f, !below, r);
+                if (below ? has_below : has_above) {
+                    uint32_t *dst = sc + pl * PLANE + (below ? 9 * PITCH : 0) + 1 + 2 * (lane & 15);
+                    dst[0] = pack4(&r[0]);
+                    dst[1] = pack4(&r[4]);
+                }
+            }
+            // image edges: the reference clamps sample indices to the padded plane (decode.swift:4245-4246):
+            // first rows (a missing row above / below is the nearest own row), then columns
+            if (!has_above || !has_below) {
+                for (int d = lane; d < 2 * PITCH; d += 64) {
+                    const int pl = d >= PITCH ? 1 : 0, c = d - pl * PITCH;
+                    uint32_t *col = sc + pl * PLANE + c;
+                    if (!has_above) col[0] = col[PITCH];
+                    if (!has_below) col[9 * PITCH] = col[8 * PITCH];
+                }
+            }
+            {
+                const int first_bad = (a.pw_c >> 2) - (sxi * CW - HX) / 4;   // first tile dword past the plane
+                if (sxi == 0 || first_bad < PITCH) {
+                    if (lane < 2 * ROWS) {
+                        uint32_t *row = sc + lane * PITCH;
+                        if (sxi == 0) row[0] = (row[1] & 0xffu) * 0x01010101u;
+                        if (first_bad < PITCH) {
+                            const uint32_t last = (row[first_bad - 1] >> 24) * 0x01010101u;
+                            for (int c = first_bad; c < PITCH; ++c) row[c] = last;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_block();
+        }
         if constexpr (IN422) {
             // pass 1: the strip's own chroma blocks (lane: plane, block row, block column)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -457,7 +618,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         //      the replication a clamped COLUMN needs is patched in LDS on edge strips only. ----
         const int cx0 = sxi * CW, cy0 = syi * CR;
         const int pwd = a.pw_c >> 2;
-        if constexpr (CHROMA && !INTHREAD && !IN422) {
+        if constexpr (CHROMA && !INSTRIP) {
             // rows of a narrow tile are packed RPI to a transfer (the LDS image is lane-linear and the
             // tile rows are contiguous): 12 transfers instead of 36 for a 16 x 4 strip of 4:2:0
             constexpr int RPI = (ROWS % (64 / PITCH) == 0) ? 64 / PITCH : 1;
@@ -510,7 +671,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         JA_PHASE(2)
 
         // ---- the chroma rows have landed (they are the only VM operations in flight) ----
-        if constexpr (CHROMA && !INTHREAD && !IN422) {
+        if constexpr (CHROMA && !INSTRIP) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int first_bad = pwd - (cx0 - HX) / 4;          // first column past the plane
             if ((HX > 0 && sxi == 0) || first_bad < PITCH) {     // wave-uniform: edge strips only
@@ -524,7 +685,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         }
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
-        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, (INTHREAD || IN422) ? 1 : 0);
+        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, INSTRIP ? 1 : 0);
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(3)
@@ -689,12 +850,12 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kT
 
 // Persistent grid = what is resident at once: workgroups per CU (LDS- and VGPR-bound, differs per
 // instantiation: 3 for 4:2:0 and grey, 2 for the variants with a full-width chroma tile) x CUs.
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX>
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false>
 int resident_workgroups()
 {
     static int cached = 0;  // one per instantiation
     if (cached == 0) {
-        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX>;
+        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX, STRIP420>;
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -714,6 +875,13 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
         hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a); \
     }
     if (!chroma) JA_K(1, 1, false)
+    else if (sx == 2 && sy == 2 && a.ccoef[0] != nullptr) {   // chroma transformed in the strip walk (IN420)
+        if constexpr (BX == 32) {
+            auto k = k_luma_fused<2, 2, MODE, true, FAST, 32, true>;
+            const int cap = resident_workgroups<2, 2, MODE, true, FAST, 32, true>();
+            hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a);
+        }
+    }
     else if (sx == 2 && sy == 2) JA_K(2, 2, true)
     else if (sx == 2 && sy == 1) JA_K(2, 1, true)
     else if (sx == 1 && sy == 2) JA_K(1, 2, true)
@@ -726,6 +894,22 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
 // costs as much as a full one: 1920 x 1080 is 7.5 x 68 strips of 32 x 2 but exactly 15 x 34 of
 // 16 x 4).  Only the 4:2:0 / 4:4:4 / grey kernels come in both shapes: the 4:2:2 and 4:4:0 chroma
 // tiles of a 16 x 4 strip would need 64 row transfers.
+inline int strip_width(int ux, int uy, int sx, int sy);
+// 4:2:0 with the chroma blocks transformed in the strip walk (IN420) instead of by k_chroma_idct: one
+// image, wide strips, at most two rounds of the resident waves' worth of strips (see the kernel)
+inline bool strip_chroma_420(const jpeg_amd_layout &L, int n_images)
+{
+#ifdef JA_X_NO_IN420
+    return false;
+#endif
+    if (L.nplanes != 3 || L.scale_x != 2 || L.scale_y != 2) return false;
+    if (strip_width(L.units_x[0], L.units_y[0], 2, 2) != 32) return false;
+#ifdef JA_X_FORCE_IN420
+    return true;
+#endif
+    const long strips = (long)((L.units_x[0] + 31) / 32) * ((L.units_y[0] + 1) / 2);
+    return n_images == 1 && strips <= 6144;
+}
 inline int strip_width(int ux, int uy, int sx, int sy)
 {
     if (sx != sy) return 32;   // (the 4:2:2 in-thread chroma passes are written for the wide strip)
@@ -765,6 +949,7 @@ bool fused_decode_supported(const jpeg_amd_layout &L, bool cosited)
 size_t fused_decode_scratch_bytes(const jpeg_amd_layout &L, int n_images)
 {
     if (L.nplanes == 1 || L.scale_y == 1) return 0;   // grey, 4:4:4, 4:2:2: no intermediate
+    if (strip_chroma_420(L, n_images)) return 0;
     const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
     return 2 * ((plane * n_images + 255) & ~(size_t)255);
 }
@@ -776,7 +961,8 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     const bool chroma = L.nplanes == 3;
     // 4:4:4: k_luma_fused transforms all three planes itself (no intermediate, no first launch)
     // 4:2:2 likewise (the chroma blocks under a strip are one per work-item; see IN422)
-    const bool inthread = chroma && L.scale_y == 1;
+    bool inthread = chroma && L.scale_y == 1;
+    if (chroma && strip_chroma_420(L, n_images)) inthread = true;   // small single 4:2:0 images too (IN420)
     LumaArgs la{};
     if (inthread) {
         for (int i = 0; i < 2; ++i) {

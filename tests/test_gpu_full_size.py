@@ -202,3 +202,18 @@ def test_planes_beyond_4GiB_are_addressed_in_64_bits(env):
         encode(m0, m1, part)
         for c, w, (ux, _), f in zip(part, whole, units, (2, 1, 1)):
             assert torch.equal(c, w[64 * ux * m0 * f:64 * ux * m1 * f]), (m0, m1)
+
+
+def test_single_image_and_batch_take_different_420_paths_and_agree(env):
+    """One 2048 x 1024 4:2:0 image goes through the single-launch kernel (chroma transformed inside
+    the strip walk), a batch of the same geometry through k_chroma_idct + k_luma_fused: same pixels,
+    both equal to the oracle, for both colour targets' RGB case and at the image's edges."""
+    e = env
+    size, n = (2048, 1024), 3
+    planes = e["synth"].natural_planes_torch(e["layout"].units(size), n, e["ctx"].torch_device, 5)
+    batch = _decode_batch(e, size, planes, n)
+    for i in range(n):
+        single = _decode_batch(e, size, [p[i:i + 1] for p in planes], 1)[0]
+        assert e["torch"].equal(single, batch[i]), f"image {i}: the two 4:2:0 paths differ"
+    want = _oracle_rgb(e, [p[1].cpu().numpy() for p in planes], size)
+    assert (batch[1].cpu().numpy().reshape(-1, 3) == want).all()

@@ -376,9 +376,14 @@ int jpeg_amd_decode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_ima
         if (!d_coef[p]) return JPEG_AMD_EINVAL;
 
     if (fused_decode_supported(*L, cosited != 0)) {
-        JA_TRY(ensure_scratch(ctx, fused_decode_scratch_bytes(*L, n_images)));
         PlaneSet cs{};
         for (int p = 0; p < L->nplanes; ++p) { cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p]; }
+        if (band_decode_supported(*L, n_images)) {
+            JA_HIP(ctx, launch_band_decode(ctx->stream, n_images, *L, cs, QuantaRef{d_quanta, quanta_stride},
+                                           color == JPEG_AMD_COLOR_RGB8, d_pixels, pixel_stride));
+            return JPEG_AMD_OK;
+        }
+        JA_TRY(ensure_scratch(ctx, fused_decode_scratch_bytes(*L, n_images)));
         JA_HIP(ctx, launch_fused_decode(ctx->stream, n_images, *L, cs, QuantaRef{d_quanta, quanta_stride},
                                         color == JPEG_AMD_COLOR_RGB8, ctx->scratch, d_pixels, pixel_stride));
         return JPEG_AMD_OK;

@@ -66,6 +66,14 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
                                const PlaneSet &coef, QuantaRef q, bool rgb, void *scratch,
                                uint8_t *d_pixels, size_t pixel_stride);
 
+// The same for ycc8 4:2:0 in ONE launch with no chroma intermediate in HBM (kernels_band.hip): a wave
+// walks down a band of 64 luma blocks and keeps the chroma samples it needs in LDS.  Chosen when the
+// call has enough independent pieces for every resident wave (large images, batches).
+bool       band_decode_supported(const jpeg_amd_layout &layout, int n_images);
+hipError_t launch_band_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &layout,
+                              const PlaneSet &coef, QuantaRef q, bool rgb, uint8_t *d_pixels,
+                              size_t pixel_stride);
+
 // ---- encode -------------------------------------------------------------------------
 // a13: Rectangular.pack
 hipError_t launch_pack(hipStream_t stream, const uint8_t *d_pixels, size_t npixels,

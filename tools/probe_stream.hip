@@ -1,0 +1,120 @@
+// probe_stream.hip -- the memory side of the fused 4:2:0 decode alone: what does HBM sustain for
+// the step's REAL footprint (read 201 MB of coefficient blocks, write 201 MB of RGB rows) as a
+// function of the tile shape, the number of resident workgroups, the load flavour (plain 16-byte
+// loads or LDS-DMA, `nt` or not) and the store flavour?  No arithmetic beyond an XOR that keeps the
+// loads alive.  VERDICT r01 task 1(b): sweep the grid and use whole-line stores / LDS-DMA reads.
+//
+// A tile is BW x BH luma blocks of an 8192 x 8192 image; persistent waves take tiles round-robin in
+// row-major order (consecutive waves = horizontally adjacent tiles), exactly like the kernels.
+//   reads : BH runs of BW x 128 B from the luma plane (pitch 1024 x 128 B) + BW x BH x 64 B of chroma
+//   writes: 8 BH pixel rows of BW x 24 B each (pitch 24 576 B)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+constexpr int W = 8192, H = 8192, UX = W / 8, UY = H / 8;
+
+__device__ __forceinline__ void lds_dma16(const void *g, unsigned lds, bool nt)
+{
+    if (nt) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(lds) : "memory");
+    else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds) : "memory");
+}
+
+// LOAD: 0 plain global_load_dwordx4, 1 LDS-DMA, 2 LDS-DMA nt;  STORE: 0 plain, 1 nt
+template <int BW, int BH, int LOAD, int STORE>
+__global__ __launch_bounds__(256) void k_stream(const unsigned char *luma, const unsigned char *chroma, unsigned char *out)
+{
+    __shared__ __attribute__((aligned(16))) u4 buf[4][LOAD ? 768 : 1];   // 12 KiB per wave for the DMA variants
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * 4;
+    constexpr int TX = UX / BW, TY = UY / BH;
+    constexpr int RUN = BW * 128;                  // bytes per luma run
+    constexpr int CH = BW * BH * 64;               // chroma bytes per tile
+    constexpr int ROWB = BW * 24;                  // bytes per pixel row of a tile
+    const size_t pitch = (size_t)W * 3;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) u4 *)buf[wave]);
+    for (int t = blockIdx.x * 4 + wave; t < TX * TY; t += nwaves) {
+        const int ty = t / TX, tx = t - ty * TX;
+        u4 acc = {0, 0, 0, 0};
+        if (LOAD == 0) {
+#pragma unroll
+            for (int r = 0; r < BH; ++r) {
+                const unsigned char *src = luma + ((size_t)(ty * BH + r) * UX + (size_t)tx * BW) * 128;
+#pragma unroll
+                for (int o = 0; o < RUN; o += 1024) acc ^= *(const u4 *)(src + o + 16 * lane);
+            }
+            const unsigned char *csrc = chroma + (size_t)t * CH;
+#pragma unroll
+            for (int o = 0; o < CH; o += 1024) acc ^= *(const u4 *)(csrc + o + 16 * lane);
+        } else {
+            int slot = 0;
+#pragma unroll
+            for (int r = 0; r < BH; ++r) {
+                const unsigned char *src = luma + ((size_t)(ty * BH + r) * UX + (size_t)tx * BW) * 128;
+#pragma unroll
+                for (int o = 0; o < RUN; o += 1024) lds_dma16(src + o + 16 * lane, lds0 + 1024 * slot++, LOAD == 2);
+            }
+            const unsigned char *csrc = chroma + (size_t)t * CH;
+#pragma unroll
+            for (int o = 0; o < CH; o += 1024) lds_dma16(csrc + o + 16 * lane, lds0 + 1024 * slot++, LOAD == 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < (BH * RUN + CH) / 1024; ++i) acc ^= buf[wave][64 * i + lane];
+        }
+        unsigned char *base = out + (size_t)(8 * BH * ty) * pitch + (size_t)tx * ROWB;
+        constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
+#pragma unroll
+        for (int y = 0; y < 8 * BH; ++y) {
+#pragma unroll
+            for (int c = 0; c < CPR; c += 64) {
+                if (c + lane < CPR) {
+                    u4 *p = (u4 *)(base + (size_t)y * pitch + 16 * (c + lane));
+                    if (STORE) __builtin_nontemporal_store(acc, p); else *p = acc;
+                }
+            }
+        }
+    }
+}
+
+typedef void (*kfn)(const unsigned char *, const unsigned char *, unsigned char *);
+struct Variant { const char *name; kfn fn; };
+
+int main(int argc, char **argv)
+{
+    const size_t out_bytes = (size_t)W * H * 3, luma_bytes = (size_t)UX * UY * 128, chroma_bytes = luma_bytes / 2;
+    const int ring = 8;
+    unsigned char *luma[ring], *chroma[ring], *out[ring];
+    for (int i = 0; i < ring; ++i) {
+        (void)hipMalloc(&luma[i], luma_bytes); (void)hipMalloc(&chroma[i], chroma_bytes); (void)hipMalloc(&out[i], out_bytes);
+        (void)hipMemset(luma[i], i + 1, luma_bytes); (void)hipMemset(chroma[i], i + 5, chroma_bytes);
+    }
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+#define V(bw, bh, ld, st) {#bw "x" #bh " load" #ld " store" #st, k_stream<bw, bh, ld, st>}
+    std::vector<Variant> vs = {
+        V(32, 2, 0, 1), V(32, 2, 2, 1), V(32, 2, 1, 1), V(32, 2, 2, 0), V(32, 2, 0, 0),
+        V(64, 1, 0, 1), V(64, 1, 2, 1), V(64, 2, 0, 1), V(64, 2, 2, 1),
+        V(16, 4, 0, 1), V(16, 4, 2, 1), V(128, 1, 0, 1), V(32, 4, 0, 1), V(32, 1, 0, 1), V(32, 1, 2, 1)};
+    const int grids[] = {256, 512, 768, 1024, 1280, 1536, 2048, 3072};
+    const double bytes = (double)(out_bytes + luma_bytes + chroma_bytes);
+    printf("%-24s", "tile / flavour  \\  WGs");
+    for (int g : grids) printf("%7d", g);
+    printf("   (GB/s, 403 MB per pass; best of 3 x 16 passes over a ring of 8 buffer sets)\n");
+    for (auto &v : vs) {
+        printf("%-24s", v.name);
+        for (int g : grids) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipEventRecord(e0);
+                for (int i = 0; i < 16; ++i) hipLaunchKernelGGL(v.fn, dim3(g), dim3(256), 0, 0, luma[i % ring], chroma[i % ring], out[i % ring]);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms / 16 < best) best = ms / 16;
+            }
+            printf("%7.0f", bytes / best / 1e6);
+        }
+        printf("\n"); fflush(stdout);
+    }
+    return 0;
+}

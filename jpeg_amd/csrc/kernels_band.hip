@@ -396,10 +396,10 @@ bool band_decode_supported(const jpeg_amd_layout &L, int n_images)
     if (band_override() < 0) return false;
     if (L.nplanes != 3 || L.scale_x != 2 || L.scale_y != 2) return false;
     if (n_images < 1 || L.units_x[1] < 1 || L.units_y[1] < 1) return false;
-    if (band_override() > 0) return true;
-    // worth it when every resident wave gets a piece of at least two chroma block rows
-    const long rows = (long)n_images * ((L.units_x[0] + kBandBlocks - 1) / kBandBlocks) * L.units_y[1];
-    return rows >= 2L * 3072;
+    // Measured (tools/ab_band.py): bit-identical, but 10-20 % slower than k_chroma_idct + k_luma_fused
+    // at every size tried -- the step is bound by VALU issue, not by the 82 MB of chroma round trip this kernel
+    // removes, and its halo / edge passes add 17 % more VALU instructions.  Kept as an opt-in.
+    return band_override() > 0;
 }
 
 hipError_t launch_band_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const PlaneSet &coef,

@@ -34,6 +34,9 @@
 #include "kernels.hpp"
 #include "upsample.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace jpeg_amd {
 
 namespace {
@@ -53,7 +56,7 @@ struct ChromaArgs {
     const uint16_t *quanta;
     size_t quanta_stride;
     int qi[2];
-    int ux, nblocks;
+    int ux, first_block, end_block;   // this launch transforms blocks [first_block, end_block) of every image
 };
 
 __global__ __launch_bounds__(kThreads) void k_chroma_idct(ChromaArgs a)
@@ -66,8 +69,8 @@ __global__ __launch_bounds__(kThreads) void k_chroma_idct(ChromaArgs a)
                                          a.quanta[img * a.quanta_stride + 64 * a.qi[pl] + zigzag_of(k, h)]);
     }
     __syncthreads();
-    const int b = blockIdx.x * kThreads + threadIdx.x;
-    if (b >= a.nblocks) return;
+    const int b = a.first_block + blockIdx.x * kThreads + threadIdx.x;
+    if (b >= a.end_block) return;
     const int by = b / a.ux, bx = b - by * a.ux;
 
     const uint4 *src = reinterpret_cast<const uint4 *>(a.coef[pl] + img * a.coef_stride[pl] + (size_t)64 * b);
@@ -114,7 +117,8 @@ struct LumaArgs {
     int W, H;
     uint8_t *out;
     size_t out_stride;
-    int tiles_x, tiles_per_image, total_tiles;
+    int tiles_x, tiles_per_image;
+    int first_tile, total_tiles;   // this launch walks strips [first_tile, total_tiles) of the call
 };
 
 // SX, SY: chroma subsampling per axis (1 or 2); MODE: 0 = YCbCr bytes, 1 = RGB bytes;
@@ -191,9 +195,19 @@ __device__ unsigned long long g_phase_cycles[4096 * 8];
 #define JA_PHASE(i)
 #endif
 
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false>
-__global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
+// Waves per SIMD a variant is built for: what its LDS footprint admits (three workgroups of ~51 KiB per CU for 4:2:0 and
+// grey; the layouts with a full-width or full-height chroma tile and 4:4:4 need 58-75 KiB per workgroup: two).
+template <int SX, int SY, bool CHROMA, bool DIRECT>
+constexpr int luma_waves_per_simd() { return DIRECT ? 4 : (CHROMA && (SX == 1 || SY == 1)) ? 2 : 3; }
+
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false>
+__global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRECT>())) void k_luma_fused(LumaArgs a)
 {
+    // DIRECT: no LDS coefficient buffer and no LDS-DMA prefetch -- a work-item loads its own block (8 x 16 B of
+    // its 128-byte line) at the top of a strip.  The wave's LDS shrinks from 12.7 to 4.5 KiB, so FOUR waves fit a
+    // SIMD (128 VGPRs): the load latency of one wave is covered by the other three, and 4 096 resident waves take
+    // the 16 384 strips of an 8192 x 8192 image in exactly four rounds (3 072 waves need 5.33: a thin last round).
+    static_assert(!DIRECT || (CHROMA && SX == 2 && SY == 2 && !STRIP420), "DIRECT is built for the two-launch 4:2:0 path");
     constexpr int BY = 64 / BX;                          // block rows per strip
     constexpr int NW = kThreads / 64;                    // waves per workgroup
     constexpr int CW = BX * 8 / SX;                      // chroma samples per strip row
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     constexpr bool IN420 = STRIP420 && CHROMA && SX == 2 && SY == 2 && BX == 32;
     constexpr bool INSTRIP = INTHREAD || IN422 || IN420;   // no k_chroma_idct in front of this kernel
     constexpr int NTAB = INSTRIP ? 3 : 1;
-    __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
+    __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][DIRECT ? 4 : 64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
     __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
@@ -373,9 +387,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
     };
 
     const int nwaves = gridDim.x * NW;
-    int s = blockIdx.x * NW + wave;
+    int s = a.first_tile + blockIdx.x * NW + wave;
     if (s >= a.total_tiles) return;
-    dma_strip(s, lane0, INSTRIP ? 1 : 0);
+    if constexpr (!DIRECT) dma_strip(s, lane0, INSTRIP ? 1 : 0);
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
 #ifdef JA_PHASE_PROFILE
@@ -410,8 +424,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         //      strip's pixel stores: when that strip took the branch-free store path (exactly
         //      2 store instructions per pixel row) only the DMA has to be waited for, not the
         //      16 stores behind it. ----
-        if (stores_behind_dma == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!DIRECT) {
+            if (stores_behind_dma == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         JA_PHASE(0)
         uint32_t w[32];
         auto read_block = [&]() {
@@ -423,7 +439,17 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                 w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
             }
         };
-        read_block();
+        if constexpr (DIRECT) {
+            const int bx = min(sxi * BX + lbx, a.ux - 1), by = min(BY * syi + seg, a.uy - 1);   // blocks outside the plane: pixels never stored
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.coef + img * a.coef_stride + ((size_t)by * a.ux + bx) * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 v = src[i];
+                w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+        } else {
+            read_block();
+        }
         if constexpr (INTHREAD) {
             // Cb, then Cr: while one plane is transformed the next one's coefficients are on their
             // way into the (single) LDS buffer -- the block has to be in registers before the DMA
@@ -664,7 +690,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         }
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
-        if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, INSTRIP ? 1 : 0);
+        if constexpr (!DIRECT) {
+            if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, INSTRIP ? 1 : 0);
+        }
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(3)
@@ -672,24 +700,34 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         // ---- chroma rows, produced just in time from the LDS tile ----
         constexpr float inv = 1.0f / (float)((SX == 2 ? 4 : 1) * (SY == 2 ? 4 : 1));
         constexpr float bias = MODE == 1 ? -127.5f : 0.5f;
-        // horizontally interpolated chroma row j of this block's patch (x4 when SX == 2)
-        auto hrow = [&](int pl, int j, float (&o)[8]) {
+        // Chroma row j of this block's patch: the LDS reads (hraw) and the conversion + horizontal
+        // interpolation, x4 when SX == 2 (hconv), are separate so that the reads can be issued one pixel row
+        // ahead of their use -- a wave that waits ~150 cycles for LDS ten times per strip leaves its SIMD to
+        // two other waves that are as likely to be waiting themselves.
+        auto hraw = [&](int pl, int j, uint32_t (&r)[3]) {
             const uint32_t *row = sc + pl * PLANE + (seg * (8 / SY) + j) * PITCH;
             if constexpr (SX == 2) {
-                const uint32_t d0 = row[lbx], d1 = row[lbx + 1], d2 = row[lbx + 2];
-                const float p[6] = {ubyte<3>(d0), ubyte<0>(d1), ubyte<1>(d1),
-                                    ubyte<2>(d1), ubyte<3>(d1), ubyte<0>(d2)};
+                r[0] = row[lbx]; r[1] = row[lbx + 1]; r[2] = row[lbx + 2];
+            } else if constexpr (INTHREAD) {   // the block's own samples, parked above
+                r[0] = sc[(pl * 16 + 2 * j) * 64 + lane]; r[1] = sc[(pl * 16 + 2 * j + 1) * 64 + lane]; r[2] = 0;
+            } else {
+                r[0] = row[2 * lbx]; r[1] = row[2 * lbx + 1]; r[2] = 0;
+            }
+        };
+        auto hconv = [&](const uint32_t (&r)[3], float (&o)[8]) {
+            if constexpr (SX == 2) {
+                const float p[6] = {ubyte<3>(r[0]), ubyte<0>(r[1]), ubyte<1>(r[1]),
+                                    ubyte<2>(r[1]), ubyte<3>(r[1]), ubyte<0>(r[2])};
                 lerp_row_2x(p, o);
             } else {
-                uint32_t d0, d1;
-                if constexpr (INTHREAD) {   // the block's own samples, parked above
-                    d0 = sc[(pl * 16 + 2 * j) * 64 + lane]; d1 = sc[(pl * 16 + 2 * j + 1) * 64 + lane];
-                } else {
-                    d0 = row[2 * lbx]; d1 = row[2 * lbx + 1];
-                }
-                o[0] = ubyte<0>(d0); o[1] = ubyte<1>(d0); o[2] = ubyte<2>(d0); o[3] = ubyte<3>(d0);
-                o[4] = ubyte<0>(d1); o[5] = ubyte<1>(d1); o[6] = ubyte<2>(d1); o[7] = ubyte<3>(d1);
+                o[0] = ubyte<0>(r[0]); o[1] = ubyte<1>(r[0]); o[2] = ubyte<2>(r[0]); o[3] = ubyte<3>(r[0]);
+                o[4] = ubyte<0>(r[1]); o[5] = ubyte<1>(r[1]); o[6] = ubyte<2>(r[1]); o[7] = ubyte<3>(r[1]);
             }
+        };
+        auto hrow = [&](int pl, int j, float (&o)[8]) {
+            uint32_t r[3];
+            hraw(pl, j, r);
+            hconv(r, o);
         };
         // final chroma value of one pixel from the vertically combined sum v
         auto finish = [&](float v) -> float {
@@ -698,9 +736,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         };
 
         float hw[2][3][8];  // SY == 2: patch rows j-1, j, j+1 of both planes (sliding window)
+        uint32_t rawn[2][3] = {{0, 0, 0}, {0, 0, 0}};   // LDS dwords of the patch row that is converted next
         if constexpr (CHROMA && SY == 2) {
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) { hrow(pl, 0, hw[pl][0]); hrow(pl, 1, hw[pl][1]); }
+            for (int pl = 0; pl < 2; ++pl) { hrow(pl, 0, hw[pl][0]); hrow(pl, 1, hw[pl][1]); hraw(pl, 2, rawn[pl]); }
+        } else if constexpr (CHROMA) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) hraw(pl, 0, rawn[pl]);
         }
 
         // ---- store geometry: per pixel row the strip's BY segments are 96 chunks of 16 B; a lane
@@ -721,9 +763,38 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
         stores_behind_dma = (FAST && full) ? 16 : 0;
         JA_PHASE(4)
 
+        // One pixel row of the strip's BY block rows at a time.  The row's LDS and memory traffic is software-
+        // pipelined behind the NEXT row's arithmetic: row y is staged (ds_write) and read back as 16-byte chunks
+        // (ds_read) right after its arithmetic, but the chunks are stored only after the arithmetic of row y + 1;
+        // the chroma dwords of the next patch row are requested a row (SY == 1) or two (SY == 2) ahead.
+        uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = make_uint4(0, 0, 0, 0);   // chunks of the previous pixel row
+        auto put = [&](uint8_t *o, const uint4 &v, int j) {
+            if constexpr (FAST) {
+                // streaming output, never re-read: non-temporal stores keep it from displacing
+                // the chroma planes in L2 / Infinity Cache (-6 % step time)
+                store_nt16(o, v);
+            } else {
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+                for (int k = 0; k < 16; ++k)
+                    if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
+            }
+        };
+        auto store_row = [&](int yy) {
+            uint8_t *rowp = strip_out + (size_t)yy * pitch;   // scalar
+#ifdef JA_X_NOSTORE  // experiment: everything but the global stores
+            if (a.W < 0)
+#endif
+            if (FAST && full) {
+                put(rowp + voff0, pv0, j0);
+                if (lane < 32) put(rowp + voff1, pv1, j1);
+            } else {
+                if (col0 && 8 * BY * syi + 8 * sg0 + yy < a.H) put(rowp + voff0, pv0, j0);
+                if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);
+            }
+        };
 #pragma unroll
         for (int y = 0; y < 8; ++y) {  // pixel row y of every block row of the strip
-            if ((y & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
             float cv[2][8];
             if constexpr (CHROMA) {
 #pragma unroll
@@ -731,7 +802,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                     if constexpr (SY == 2) {
                         // window holds patch rows (y>>1), (y>>1)+1, (y>>1)+2; the nearer row
                         // (middle) weighs 3, the farther one (above for even y, below for odd) 1
-                        if ((y & 1) == 1) hrow(pl, (y >> 1) + 2, hw[pl][2]);
+                        if ((y & 1) == 1) hconv(rawn[pl], hw[pl][2]);
 #pragma unroll
                         for (int x = 0; x < 8; ++x)
                             cv[pl][x] = finish(w31(hw[pl][1][x], hw[pl][(y & 1) ? 2 : 0][x]));
@@ -741,7 +812,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                         }
                     } else {
                         float h[8];
-                        hrow(pl, y, h);
+                        hconv(rawn[pl], h);
 #pragma unroll
                         for (int x = 0; x < 8; ++x) cv[pl][x] = finish(h[x]);
                     }
@@ -785,38 +856,31 @@ __global__ __launch_bounds__(kThreads, 3) void k_luma_fused(LumaArgs a)
                 d[(3 * x + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c1, (3 * x + 1) & 3, d[(3 * x + 1) >> 2]);
                 d[(3 * x + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c2, (3 * x + 2) & 3, d[(3 * x + 2) >> 2]);
             }
-            // stage the row (LDS ops of one wave execute in order), then store 16-byte chunks
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the row's traffic: store the PREVIOUS row's chunks (their LDS read was issued a row ago), stage
+            //      this row (LDS ops of one wave execute in order) and read it back as chunks, request the chroma
+            //      dwords of the next patch row ----
+            if (y > 0) store_row(y - 1);
             uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
             sw[0] = make_uint2(d[0], d[1]);
             sw[1] = make_uint2(d[2], d[3]);
             sw[2] = make_uint2(d[4], d[5]);
-            {
-                uint8_t *rowp = strip_out + (size_t)y * pitch;   // scalar
-                const uint4 v0 = *reinterpret_cast<const uint4 *>(stage_w + 4 * lane);
-                const uint4 v1 = *reinterpret_cast<const uint4 *>(stage_w + 4 * (64 + (lane & 31)));
-                auto put = [&](uint8_t *o, const uint4 &v, int j) {
-                    if constexpr (FAST) {
-                        // streaming output, never re-read: non-temporal stores keep it from displacing
-                        // the chroma planes in L2 / Infinity Cache (-6 % step time)
-                        store_nt16(o, v);
-                    } else {
-                        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-                        for (int k = 0; k < 16; ++k)
-                            if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
+            pv0 = *reinterpret_cast<const uint4 *>(stage_w + 4 * lane);
+            pv1 = *reinterpret_cast<const uint4 *>(stage_w + 4 * (64 + (lane & 31)));
+            if constexpr (CHROMA) {
+                if constexpr (SY == 2) {
+                    if ((y & 1) == 1 && y < 7) {
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) hraw(pl, (y >> 1) + 3, rawn[pl]);
                     }
-                };
-#ifdef JA_X_NOSTORE  // experiment: everything but the global stores
-                if (a.W < 0)
-#endif
-                if (FAST && full) {
-                    put(rowp + voff0, v0, j0);
-                    if (lane < 32) put(rowp + voff1, v1, j1);
-                } else {
-                    if (col0 && 8 * BY * syi + 8 * sg0 + y < a.H) put(rowp + voff0, v0, j0);
-                    if (col1 && 8 * BY * syi + 8 * sg1 + y < a.H) put(rowp + voff1, v1, j1);
+                } else if (y < 7) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) hraw(pl, y + 1, rawn[pl]);
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        store_row(7);
         JA_PHASE(5)
     }
 #ifdef JA_PHASE_PROFILE
@@ -829,12 +893,12 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kT
 
 // Persistent grid = what is resident at once: workgroups per CU (LDS- and VGPR-bound, differs per
 // instantiation: 3 for 4:2:0 and grey, 2 for the variants with a full-width chroma tile) x CUs.
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false>
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false>
 int resident_workgroups()
 {
     static int cached = 0;  // one per instantiation
     if (cached == 0) {
-        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX, STRIP420>;
+        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX, STRIP420, DIRECT>;
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -842,6 +906,13 @@ int resident_workgroups()
         cached = per_cu * cus;
     }
     return cached;
+}
+
+// development switch: JPEG_AMD_DIRECT=1 selects the four-waves-per-SIMD variant of the 4:2:0 luma kernel
+inline bool direct_420()
+{
+    static const bool v = [] { const char *e = std::getenv("JPEG_AMD_DIRECT"); return e && e[0] == '1'; }();
+    return v;
 }
 
 template <int MODE, bool FAST, int BX>
@@ -860,6 +931,11 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
             const int cap = resident_workgroups<2, 2, MODE, true, FAST, 32, true>();
             hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a);
         }
+    }
+    else if (sx == 2 && sy == 2 && direct_420()) {
+        auto k = k_luma_fused<2, 2, MODE, true, FAST, BX, false, true>;
+        const int cap = resident_workgroups<2, 2, MODE, true, FAST, BX, false, true>();
+        hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a);
     }
     else if (sx == 2 && sy == 2) JA_K(2, 2, true)
     else if (sx == 2 && sy == 1) JA_K(2, 1, true)
@@ -933,16 +1009,55 @@ size_t fused_decode_scratch_bytes(const jpeg_amd_layout &L, int n_images)
     return 2 * ((plane * n_images + 255) & ~(size_t)255);
 }
 
+namespace {
+
+// one k_luma_fused launch over strips [la.first_tile, la.total_tiles)
+hipError_t launch_luma_any(hipStream_t stream, const LumaArgs &la, int bx, int sx, int sy, bool chroma, bool rgb, bool fast)
+{
+    // grid == resident capacity (launch_luma clamps).  (Sizing it so that every wave gets the same number of
+    // strips -- fewer waves, no thin last round -- measured 4 % slower; 2 instead of 3 workgroups per CU 3.5 %.)
+    const int wgs = (la.total_tiles - la.first_tile + 3) / 4;
+    if (wgs <= 0) return hipSuccess;
+#define JA_L(BX_)                                                                     \
+    {                                                                                 \
+        if (fast)                                                                     \
+            return rgb ? launch_luma<1, true, BX_>(stream, wgs, la, sx, sy, chroma)   \
+                       : launch_luma<0, true, BX_>(stream, wgs, la, sx, sy, chroma);  \
+        return rgb ? launch_luma<1, false, BX_>(stream, wgs, la, sx, sy, chroma)      \
+                   : launch_luma<0, false, BX_>(stream, wgs, la, sx, sy, chroma);     \
+    }
+    if (bx == 16) JA_L(16)
+    JA_L(32)
+#undef JA_L
+}
+
+// JPEG_AMD_OVERLAP=1 pipelines the two launches of a 4:2:0 / 4:4:0 decode over parts of the call on the context's
+// helper streams (OverlapLanes).  OFF by default -- measured on MI355X (tools/ab_band.py --env=JPEG_AMD_OVERLAP):
+// the cross-stream event waits cost more than the overlap returns.  One 8192 x 8192 image as two halves 139 us
+// against 103 us on one stream, 16 x 2048 x 2048 141 vs 102 us, 512 x 1080p as eight groups 1 506 vs 1 525 us.
+inline bool overlap_enabled()
+{
+    static const bool v = [] { const char *e = std::getenv("JPEG_AMD_OVERLAP"); return e && e[0] == '1'; }();
+    return v;
+}
+
+}  // namespace
+
+bool fused_decode_wants_lanes() { return overlap_enabled(); }
+
 hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L,
                                const PlaneSet &coef, QuantaRef q, bool rgb, void *scratch,
-                               uint8_t *d_pixels, size_t pixel_stride)
+                               uint8_t *d_pixels, size_t pixel_stride, const OverlapLanes *lanes)
 {
     const bool chroma = L.nplanes == 3;
     // 4:4:4: k_luma_fused transforms all three planes itself (no intermediate, no first launch)
     // 4:2:2 likewise (the chroma blocks under a strip are one per work-item; see IN422)
     bool inthread = chroma && L.scale_y == 1;
     if (chroma && strip_chroma_420(L, n_images)) inthread = true;   // small single 4:2:0 images too (IN420)
+    const bool two_launches = chroma && !inthread;
     LumaArgs la{};
+    ChromaArgs ca{};
+    const size_t cplane = chroma ? (size_t)64 * L.units_x[1] * L.units_y[1] : 0;
     if (inthread) {
         for (int i = 0; i < 2; ++i) {
             la.ccoef[i] = static_cast<const int16_t *>(coef.ptr[1 + i]);
@@ -951,28 +1066,17 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
         }
         la.pw_c = 8 * L.units_x[1]; la.ph_c = 8 * L.units_y[1];
     } else if (chroma) {
-        const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
-        const size_t half = (plane * n_images + 255) & ~(size_t)255;
-        ChromaArgs ca{};
+        const size_t half = (cplane * n_images + 255) & ~(size_t)255;
         for (int i = 0; i < 2; ++i) {
             ca.coef[i] = static_cast<const int16_t *>(coef.ptr[1 + i]);
             ca.coef_stride[i] = coef.stride[1 + i];
             ca.out[i] = static_cast<uint8_t *>(scratch) + i * half;
             ca.qi[i] = L.qi[1 + i];
         }
-        ca.out_stride = plane;
+        ca.out_stride = cplane;
         ca.quanta = q.d_quanta; ca.quanta_stride = q.image_stride;
-        ca.ux = L.units_x[1]; ca.nblocks = L.units_x[1] * L.units_y[1];
-#ifdef JA_X_SKIPK1
-        if (false) {
-#else
-        if (ca.nblocks > 0) {
-#endif
-            hipLaunchKernelGGL(k_chroma_idct, dim3(blocks_for(ca.nblocks), n_images, 2), dim3(kThreads), 0, stream, ca);
-            const hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return e;
-        }
-        la.cb = ca.out[0]; la.cr = ca.out[1]; la.c_stride = plane;
+        ca.ux = L.units_x[1]; ca.first_block = 0; ca.end_block = L.units_x[1] * L.units_y[1];
+        la.cb = ca.out[0]; la.cr = ca.out[1]; la.c_stride = cplane;
         la.pw_c = 8 * L.units_x[1]; la.ph_c = 8 * L.units_y[1];
     }
     la.coef = static_cast<const int16_t *>(coef.ptr[0]);
@@ -987,28 +1091,85 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     la.tiles_x = (la.ux + bx - 1) / bx;
     const int strips_y = (la.uy + by - 1) / by;
     la.tiles_per_image = la.tiles_x * strips_y;
+    la.first_tile = 0;
     la.total_tiles = la.tiles_per_image * n_images;
     if (la.total_tiles == 0) return hipSuccess;
-#ifdef JA_X_SKIPK2
-    return hipSuccess;
-#endif
-    // grid == resident capacity.  (Sizing it so that every wave gets the same number of strips --
-    // fewer waves, no thin last round -- measured 4 % slower; 2 instead of 3 workgroups per CU
-    // is 3.5 % slower.)
-    const int wgs = (la.total_tiles + 3) / 4;
     const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-#define JA_L(BX_)                                                                     \
-    {                                                                                 \
-        if (fast)                                                                     \
-            return rgb ? launch_luma<1, true, BX_>(stream, wgs, la, sx, sy, chroma)   \
-                       : launch_luma<0, true, BX_>(stream, wgs, la, sx, sy, chroma);  \
-        return rgb ? launch_luma<1, false, BX_>(stream, wgs, la, sx, sy, chroma)      \
-                   : launch_luma<0, false, BX_>(stream, wgs, la, sx, sy, chroma);     \
+
+    // one k_chroma_idct launch: blocks [b0, b1) of images [i0, i1)
+    auto launch_chroma = [&](hipStream_t st, int i0, int i1, int b0, int b1) -> hipError_t {
+#ifdef JA_X_SKIPK1
+        return hipSuccess;
+#endif
+        if (b1 <= b0 || i1 <= i0) return hipSuccess;
+        ChromaArgs c = ca;
+        for (int i = 0; i < 2; ++i) { c.coef[i] += (size_t)i0 * c.coef_stride[i]; c.out[i] += (size_t)i0 * c.out_stride; }
+        c.quanta += (size_t)i0 * c.quanta_stride;
+        c.first_block = b0; c.end_block = b1;
+        hipLaunchKernelGGL(k_chroma_idct, dim3(blocks_for(b1 - b0), i1 - i0, 2), dim3(kThreads), 0, st, c);
+        return hipGetLastError();
+    };
+    auto launch_strips = [&](hipStream_t st, int t0, int t1) -> hipError_t {
+#ifdef JA_X_SKIPK2
+        return hipSuccess;
+#endif
+        LumaArgs l = la;
+        l.first_tile = t0; l.total_tiles = t1;
+        return launch_luma_any(st, l, bx, sx, sy, chroma, rgb, fast);
+    };
+
+    // ---- parts: groups of images of a batch, or the upper and lower half of one large image ----
+    constexpr int kPartTiles = 6144;   // two rounds of the resident waves: below that a part is mostly ramp and tail
+    int nparts = 1;
+    if (two_launches && lanes && overlap_enabled()) {
+        if (n_images > 1) nparts = (int)std::min<long>(std::min<long>(OverlapLanes::kMaxParts, n_images), la.total_tiles / kPartTiles);
+        else if (la.total_tiles >= 2 * kPartTiles && strips_y >= 4) nparts = 2;
+        if (nparts < 2) nparts = 1;
     }
-    if (bx == 16) JA_L(16)
-    JA_L(32)
-#undef JA_L
+    if (nparts == 1) {
+        if (two_launches) {
+            const hipError_t e = launch_chroma(stream, 0, n_images, 0, ca.end_block);
+            if (e != hipSuccess) return e;
+        }
+        return launch_strips(stream, 0, la.total_tiles);
+    }
+
+#define JA_CHECK(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+    JA_CHECK(hipEventRecord(lanes->entered, stream));
+    JA_CHECK(hipStreamWaitEvent(lanes->chroma, lanes->entered, 0));
+    JA_CHECK(hipStreamWaitEvent(lanes->luma2, lanes->entered, 0));
+    int t_begin[OverlapLanes::kMaxParts + 1];
+    if (n_images > 1) {
+        for (int p = 0; p <= nparts; ++p) {
+            const int img = (int)((long)n_images * p / nparts);
+            t_begin[p] = img * la.tiles_per_image;
+        }
+        for (int p = 0; p < nparts; ++p) {
+            JA_CHECK(launch_chroma(lanes->chroma, t_begin[p] / la.tiles_per_image, t_begin[p + 1] / la.tiles_per_image, 0, ca.end_block));
+            JA_CHECK(hipEventRecord(lanes->chroma_done[p], lanes->chroma));
+        }
+    } else {
+        // strip rows [0, mid) and [mid, strips_y).  The upper half reads chroma sample rows up to the first row of the
+        // chroma block row under strip row `mid` (the bilinear filter reaches one sample down, decode.swift:4243-4257):
+        // the first chroma launch goes one block row further than the half; the lower half needs both launches.
+        const int mid = strips_y / 2;
+        const int c_mid = std::min(L.units_y[1], (mid * by * 8 / sy) / 8 + 1);
+        t_begin[0] = 0; t_begin[1] = mid * la.tiles_x; t_begin[2] = la.total_tiles;
+        JA_CHECK(launch_chroma(lanes->chroma, 0, 1, 0, c_mid * L.units_x[1]));
+        JA_CHECK(hipEventRecord(lanes->chroma_done[0], lanes->chroma));
+        JA_CHECK(launch_chroma(lanes->chroma, 0, 1, c_mid * L.units_x[1], ca.end_block));
+        JA_CHECK(hipEventRecord(lanes->chroma_done[1], lanes->chroma));
+    }
+    for (int p = 0; p < nparts; ++p) {
+        hipStream_t st = (p & 1) ? lanes->luma2 : stream;
+        JA_CHECK(hipStreamWaitEvent(st, lanes->chroma_done[p], 0));
+        JA_CHECK(launch_strips(st, t_begin[p], t_begin[p + 1]));
+    }
+    JA_CHECK(hipEventRecord(lanes->luma2_done, lanes->luma2));
+    JA_CHECK(hipStreamWaitEvent(stream, lanes->luma2_done, 0));
+#undef JA_CHECK
+    return hipSuccess;
 }
 
 }  // namespace jpeg_amd

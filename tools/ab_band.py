@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the band-walk 4:2:0 decode (kernels_band.hip) against the two-launch path: same inputs through
-both (JPEG_AMD_BAND=1 / 0 in two child processes), output digests compared, times side by side.
-Development aid; needs a GPU.  usage: tools/ab_band.py [--quick]"""
+"""A/B of a development switch of the fused 4:2:0 decode (default JPEG_AMD_BAND: the band-walk kernel of
+kernels_band.hip against the two-launch path): same inputs through both settings (=0 / =1 in two child
+processes), output digests compared, times side by side.
+Development aid; needs a GPU.  usage: tools/ab_band.py [--quick] [--env=JPEG_AMD_DIRECT]"""
 import sys, os, subprocess, json, hashlib, ctypes as C
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,8 +46,12 @@ def child():
 
 def main():
     res = {}
+    var = "JPEG_AMD_BAND"
+    for a in sys.argv[1:]:
+        if a.startswith("--env="): var = a[6:]
     for mode in ("0", "1"):
-        env = dict(os.environ, JPEG_AMD_BAND=mode)
+        env = dict(os.environ)
+        env[var] = mode
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + [a for a in sys.argv[1:]], env=env,
                            capture_output=True, text=True)
         if p.returncode != 0:
@@ -58,7 +63,7 @@ def main():
         same = a["rgb_sha"] == b["rgb_sha"] and a["ycc_sha"] == b["ycc_sha"]
         bad += not same
         W, H, N = a["case"]
-        print(f"{N:4d} x {W}x{H}: two-launch RGB {a['rgb_us']:8.1f} YCC {a['ycc_us']:8.1f} us | band RGB {b['rgb_us']:8.1f} YCC {b['ycc_us']:8.1f} us | "
+        print(f"{N:4d} x {W}x{H}: {var}=0 RGB {a['rgb_us']:8.1f} YCC {a['ycc_us']:8.1f} us | =1 RGB {b['rgb_us']:8.1f} YCC {b['ycc_us']:8.1f} us | "
               f"{'identical' if same else 'DIFFERENT'}")
     sys.exit(1 if bad else 0)
 

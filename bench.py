@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X spectral pipeline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c5] [--no-extras]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|c3|c5] [--no-extras]
 
 Metric (BASELINE.json): Mpixels/s of device-resident fused decode
 (dequant + IDCT + 4:2:0 upsample + YCbCr->RGB), and its fraction of the HBM roofline.
@@ -9,12 +9,18 @@ A step = one pass of jpeg_amd_decode_batch over one batch of synthetic coefficie
 already resident in HBM (host Huffman decoding and PCIe transfers are out of scope and
 excluded; see DESIGN.md "Measurement").
 
-Workload c3 (default, BASELINE.json configs[2]): one 8192x8192 ycc8 4:2:0 image per GPU per
-step; the step rotates through a ring of distinct images so that the 256 MiB Infinity
-Cache cannot serve the input.  Workload c5 (configs[4]): 512 images of 1920x1080 per GPU
-per step (= 4096 images over 8 GPUs).  Scaling is weak: every rank decodes its own
-independent images, there is no data-path collective; the only collective is an RCCL
-broadcast of the quantisation tables from rank 0 before the timed region.
+Workload c3 (BASELINE.json configs[2], the configuration the metric is quoted on; the default at
+N = 1): one 8192x8192 ycc8 4:2:0 image per GPU per step; the step rotates through a ring of distinct
+images so that the 256 MiB Infinity Cache cannot serve the input.  With --gpus N > 1 it scales weakly
+(every rank its own image).
+Workload c5 (configs[4]; the default at N > 1): ONE job of 4096 independent 1920x1080 images per
+step, sharded over the ranks with jpeg_amd.dist.shard (contiguous chunks: 512 per GPU at N = 8, all
+4096 = 51 GB of coefficients + pixels on the one GPU at N = 1) -- strong scaling.  At N = 1 the
+default line also carries the same job in `extra.c5_4096x1080p`, so that a 1/2/4/8 curve has its
+N = 1 point on the same workload.
+There is no data-path collective in either workload: every rank decodes its own independent images;
+the only collective is an RCCL broadcast of the quantisation tables from rank 0 before the timed
+region.
 
 For N > 1 launch with:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
@@ -42,7 +48,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "c3", "c5"],
+                    help="auto: c3 at N = 1 (the headline), c5 at N > 1 (4096 x 1080p sharded over the ranks)")
+    ap.add_argument("--c5-images", type=int, default=4096, help="images of the c5 job (all ranks together)")
     ap.add_argument("--ring", type=int, default=0, help="distinct image sets to rotate through")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2/C4/C5 side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -71,6 +79,7 @@ class DecodeWorkload:
         self.out = torch.empty((ring * n_images, self.pixel_stride), dtype=torch.uint8, device=dev)
         self.d_quanta = quanta            # device tensor int16 view of uint16 [2][64]
         self.blocks = sum(ux * uy for ux, uy in self.units)
+        self.pixels_per_image = width * height
         self.pixels = width * height * n_images
         # algorithmic bytes per step: coefficients in + RGB8 out
         self.bytes = (128 * self.blocks + 3 * width * height) * n_images
@@ -91,6 +100,16 @@ class DecodeWorkload:
         if st != 0:
             raise self._lib.JpegAmdError(st, "jpeg_amd_decode_batch", 0)
 
+    def timer_begin(self):
+        self.ctx.timer_begin()
+
+    def timer_end(self):
+        return self.ctx.timer_end()
+
+    def device_name(self):
+        import torch
+        return torch.cuda.get_device_name(self.ctx.torch_device)
+
     def host_case(self, image=0):
         """Coefficient planes and the pixels the device produced for one image of the LAST step:
         what the cpu_baseline leg decodes again on the host and compares (not timed)."""
@@ -98,15 +117,16 @@ class DecodeWorkload:
         return planes, self.out[image].cpu().numpy().reshape(-1, 3)
 
 
-def time_region(ctx, fn, steps, sync, barrier):
-    """Barrier + synchronize on both sides; returns (wall seconds, GPU-event ms)."""
+def time_region(wl, fn, steps, sync, barrier):
+    """Barrier + synchronize on both sides; returns (wall seconds, device-event ms: HIP events on the stream the
+    kernels are launched on, via the workload's timer)."""
     barrier()
     sync()
     t0 = time.perf_counter()
-    ctx.timer_begin()
+    wl.timer_begin()
     for _ in range(steps):
         fn()
-    gpu_ms = ctx.timer_end()
+    gpu_ms = wl.timer_end()
     sync()
     barrier()
     return time.perf_counter() - t0, gpu_ms
@@ -178,101 +198,144 @@ def cpu_baseline(J, quanta_np, seconds, device_case=None, encode_case=None):
     }
 
 
-def main():
-    args = parse()
+def kernel_source_sha16():
+    """Digest of the device sources of the decode path: `roofline.traffic` (a rocprofv3 PMC measurement kept in
+    profiles/traffic_latest.json) is only reported while it belongs to the kernels that are being timed."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels_fused.hip", "dct.hpp", "upsample.hpp", "kernels.hpp"):
+        h.update(open(os.path.join(ROOT, "jpeg_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
+    """One rank of the benchmark.  `make_workload(name, width, height, n_images, ring, quanta, seed)` builds the
+    object whose step() is timed (default: DecodeWorkload on this rank's GPU); tests/ drives this same function
+    under gloo on CPU with an oracle-backed workload.  Returns the result dict on rank 0, None elsewhere."""
     import numpy as np
     import torch
     import jpeg_amd as J
-    from jpeg_amd import _lib
+    from jpeg_amd import dist as jd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 with python -m torch.distributed.run (see module docstring)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with python -m torch.distributed.run "
+                         "(see module docstring)")
+    if device_kind == "cuda":
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        dev = torch.device("cpu")
 
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if device_kind == "cuda":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world and dist.get_rank() == rank
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
     def sync():
-        torch.cuda.synchronize(dev)
+        if device_kind == "cuda":
+            torch.cuda.synchronize(dev)
 
-    ctx = J.Context(local)
+    ctx = J.Context(local) if device_kind == "cuda" else None
 
     # quantisation tables: rank 0 owns them, RCCL broadcast over xGMI is the only collective
-    from jpeg_amd import dist as jd
     q_np = np.stack([J.compression_quanta("luminance", 1.0), J.compression_quanta("chrominance", 1.0)])
     d_quanta = jd.broadcast_quanta(q_np if rank == 0 else 2, 0, dev, dist)
     if dist is not None:
         assert (d_quanta.cpu().numpy().view(np.uint16) == q_np).all()
 
-    if args.workload == "c3":
+    workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c5")
+    if make_workload is None:
+        def make_workload(name, width, height, n_images, ring, quanta, seed):
+            return DecodeWorkload(J, ctx, width, height, n_images, ring, quanta, seed)
+    if workload == "c3":
         ring = args.ring or 8
-        wl = DecodeWorkload(J, ctx, 8192, 8192, 1, ring, d_quanta, seed=20240807 + 1000 * rank)
+        wl = make_workload("c3", 8192, 8192, 1, ring, d_quanta, 20240807 + 1000 * rank)
+        scaling, images_total = "weak", world
         name = ("C3: one 8192x8192 ycc8 4:2:0 image per GPU per step, fused Spectral->RGB8 decode "
                 f"(ring of {ring} distinct images)")
+        parallelism = f"independent images x{world} (weak scaling), no data-path collective"
     else:
-        ring = args.ring or 2
-        wl = DecodeWorkload(J, ctx, 1920, 1080, 512, ring, d_quanta, seed=20240807 + 1000 * rank)
-        name = ("C5: 512 images of 1920x1080 ycc8 4:2:0 per GPU per step, fused Spectral->RGB8 decode "
-                f"(ring of {ring} distinct batches)")
+        # ONE job of args.c5_images independent images, contiguous shards (jpeg_amd.dist.shard)
+        lo, hi = jd.shard(args.c5_images, rank, world)
+        ring = args.ring or (2 if (hi - lo) <= 1024 else 1)   # 12.4 MB per image and ring slot; the set is >> 256 MiB anyway
+        wl = make_workload("c5", 1920, 1080, hi - lo, ring, d_quanta, 20240807 + lo)
+        scaling, images_total = "strong", args.c5_images
+        name = (f"C5: {args.c5_images} independent 1920x1080 ycc8 4:2:0 images per step, sharded over {world} GPU(s) "
+                f"({hi - lo} on rank 0), fused Spectral->RGB8 decode (ring of {ring} distinct batches)")
+        parallelism = f"images sharded contiguously over {world} rank(s) (strong scaling), no data-path collective"
 
     for _ in range(args.warmup):
         wl.step()
-    wall, gpu_ms = time_region(ctx, wl.step, args.steps, sync, barrier)
-
+    wall, gpu_ms = time_region(wl, wl.step, args.steps, sync, barrier)
     wall_max = jd.max_over_ranks(wall, dev, dist)
+
+    # per-rank record (device, images, times), gathered on every rank; rank 0 reports it
+    mine = {"rank": rank, "device": wl.device_name(), "images_per_step": wl.n_images,
+            "wall_ms_per_step": round(wall / args.steps * 1e3, 5), "gpu_ms_per_step": round(gpu_ms / args.steps, 5)}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        assert sum(r["images_per_step"] for r in per_rank) == images_total
 
     result = None
     if rank == 0:
-        total_px = wl.pixels * args.steps * world
-        value = total_px / wall_max / 1e6
+        pixels_per_step = wl.pixels_per_image * images_total
+        value = pixels_per_step * args.steps / wall_max / 1e6
         gpu_s_per_step = gpu_ms / 1e3 / args.steps
         achieved = wl.bytes / gpu_s_per_step / 1e9
-        traffic = None
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and device_kind == "cuda":
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload:
+                if tj.get("workload") != workload:
+                    traffic_note = f"profiles/traffic_latest.json is for workload {tj.get('workload')}"
+                elif tj.get("kernel_source_sha16") != kernel_source_sha16():
+                    traffic_note = ("stale: profiles/traffic_latest.json was measured at commit "
+                                    f"{tj.get('commit')} with other kernel sources")
+                else:
                     traffic = tj.get("hbm_bytes_per_step")
-            except Exception:
-                traffic = None
+                    traffic_note = f"rocprofv3 PMC passes of this command at commit {tj.get('commit')} (tools/profile_round.sh)"
+            except Exception as e:
+                traffic_note = repr(e)
         result = {
             "metric": "Mpixels/s decode (IDCT+dequant+upsample+YCbCr->RGB); % HBM roofline",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall_max / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "image": list(wl.size), "images_per_gpu_per_step": wl.n_images,
+            "config": {"workload": name, "image": list(wl.size), "images_per_step_all_ranks": images_total,
                        "sampling": "4:2:0", "output": "RGB8", "coefficients": "distribution N (SURVEY 8d), seeded",
-                       "quanta": "CompressionLevel luminance/chrominance(1.0)",
-                       "parallelism": f"independent images x{world}, no data-path collective"},
+                       "quanta": "CompressionLevel luminance/chrominance(1.0)", "parallelism": parallelism},
+            "per_rank": per_rank,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_note,
                          "algorithmic_bytes_per_step": wl.bytes,
                          "gpu_ms_per_step_hip_events": round(gpu_s_per_step * 1e3, 5),
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
-                         "kernels": "all kernels of one fused decode step (rank 0)"},
+                         "kernels": "all kernels of one fused decode step (rank 0's shard)"},
         }
 
     # ---- not timed: side measurements, CPU baseline (+ parity of what was just measured) ----
-    if rank == 0:
+    if rank == 0 and device_kind == "cuda":
         encode_case = None
         if world == 1 and not args.no_extras:
-            result["extra"] = extras(J, ctx, d_quanta, q_np, sync, args)
+            result["extra"] = extras(J, ctx, d_quanta, q_np, sync, args, workload)
             encode_case = result["extra"].pop("_c4_host_case", None)
             # what the vendor's device-to-device memcpy moves on THIS box (read + written bytes per
             # second), measured just now: the practical ceiling of a 1 : 1 read / write stream
@@ -293,13 +356,19 @@ def main():
             result["parity_vs_oracle"] = parity.get("decode_equals_cpu")
             if "encode_equals_cpu" in parity and "extra" in result:
                 result["extra"]["c4_encode_4096"]["coefficients_equal_oracle"] = parity["encode_equals_cpu"]
+    if rank == 0:
         print(json.dumps(result), flush=True)
     barrier()
     if dist is not None:
         dist.destroy_process_group()
+    return result
 
 
-def extras(J, ctx, d_quanta, q_np, sync, args):
+def main():
+    run(parse())
+
+
+def extras(J, ctx, d_quanta, q_np, sync, args, workload="c3"):
     """Short side measurements of the other BASELINE.json configurations (N = 1 only)."""
     import numpy as np
     import torch
@@ -395,20 +464,25 @@ def extras(J, ctx, d_quanta, q_np, sync, args):
         out["c4_encode_4096"]["parity_error"] = repr(e)
     del px, coefs
 
-    # C5-shaped batch on one GPU: 128 images of 1920x1080 (a quarter of the per-GPU share)
-    if args.workload != "c5":
-        wl = DecodeWorkload(J, ctx, 1920, 1080, 128, 2, d_quanta, seed=5)
-        for _ in range(2):
+    # C5 on this one GPU: the whole job of BASELINE.json configs[4] (4096 images of 1920x1080: 51 GB of
+    # coefficients + pixels) -- the N = 1 point of the 1/2/4/8 curve on the SAME workload `--gpus N` runs
+    if workload != "c5":
+        try:
+            wl = DecodeWorkload(J, ctx, 1920, 1080, args.c5_images, 1, d_quanta, seed=20240807)
             wl.step()
-        sync()
-        ctx.timer_begin()
-        n = 10
-        for _ in range(n):
-            wl.step()
-        ms = ctx.timer_end() / n
-        out["c5_batch_128x1080p"] = {"ms": round(ms, 4), "Mpixels_per_s": round(wl.pixels / ms / 1e3, 1),
-                                     "GB_per_s": round(wl.bytes / ms / 1e6, 1),
-                                     "frac_hbm": round(wl.bytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            sync()
+            ctx.timer_begin()
+            n = 5
+            for _ in range(n):
+                wl.step()
+            ms = ctx.timer_end() / n
+            out["c5_%dx1080p" % args.c5_images] = {
+                "images": args.c5_images, "ms": round(ms, 4), "Mpixels_per_s": round(wl.pixels / ms / 1e3, 1),
+                "GB_per_s": round(wl.bytes / ms / 1e6, 1), "frac_hbm": round(wl.bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                "note": "same job as `bench.py --gpus N` (workload c5), all images on this GPU"}
+            del wl
+        except Exception as e:  # never let a side measurement break the headline line
+            out["c5_%dx1080p" % args.c5_images] = {"error": repr(e)}
     # File path, PCIe inclusive (never the headline `value`): 1080p 4:2:0 baseline JPEG bytes in host
     # memory -> RGB bytes in host memory; host threads entropy-decode while the device works on
     # the previous chunk (jpeg_amd_decompress_batch).  The files come from this library's encoder.

@@ -198,21 +198,25 @@ __device__ unsigned long long g_phase_cycles[4096 * 8];
 // Waves per SIMD a variant is built for: what its LDS footprint admits (three workgroups of ~51 KiB per CU for 4:2:0 and
 // grey; the layouts with a full-width or full-height chroma tile and 4:4:4 need 58-75 KiB per workgroup: two).
 template <int SX, int SY, bool CHROMA, bool DIRECT>
-constexpr int luma_waves_per_simd() { return DIRECT ? 4 : (CHROMA && (SX == 1 || SY == 1)) ? 2 : 3; }
+constexpr int luma_waves_per_simd() { return (CHROMA && (SX == 1 || SY == 1)) ? 2 : 3; }
 
 template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false>
 __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRECT>())) void k_luma_fused(LumaArgs a)
 {
-    // DIRECT: no LDS coefficient buffer and no LDS-DMA prefetch -- a work-item loads its own block (8 x 16 B of
-    // its 128-byte line) at the top of a strip.  The wave's LDS shrinks from 12.7 to 4.5 KiB, so FOUR waves fit a
-    // SIMD (128 VGPRs): the load latency of one wave is covered by the other three, and 4 096 resident waves take
-    // the 16 384 strips of an 8192 x 8192 image in exactly four rounds (3 072 waves need 5.33: a thin last round).
+    // DIRECT: no LDS coefficient buffer and no LDS-DMA -- a work-item loads its own block (8 x 16 B of its 128-byte
+    // line) straight into registers, one strip AHEAD: the loads for the next strip are issued in the middle of the
+    // pixel rows, when half of the luma samples are consumed and their registers are free.  Saves the 8 DMA
+    // instructions per strip (60-185 cycles each to issue), the LDS read-back and its wait.
     static_assert(!DIRECT || (CHROMA && SX == 2 && SY == 2 && !STRIP420), "DIRECT is built for the two-launch 4:2:0 path");
     constexpr int BY = 64 / BX;                          // block rows per strip
     constexpr int NW = kThreads / 64;                    // waves per workgroup
     constexpr int CW = BX * 8 / SX;                      // chroma samples per strip row
     constexpr int CR = BY * 8 / SY;                      // chroma rows under a strip
-    constexpr int HX = SX == 2 ? 4 : 0;                  // halo bytes per side (keeps dword alignment)
+    // halo bytes per side.  The tiles that k_chroma_idct's planes are copied into by LDS-DMA carry 16: a tile row is
+    // then a whole number of 16-byte chunks and the copy takes 4-5 DMA instructions of 16 B per lane instead of
+    // 20-36 of 4 B (an LDS-DMA instruction costs 60-185 cycles to ISSUE whatever it moves: the 20 row transfers of
+    // a 32 x 2 strip were 15 % of the strip's wall time).  The tiles the strip fills itself keep 4.
+    constexpr int HX = SX == 2 ? ((STRIP420 || (SX == 2 && SY == 1 && BX == 32)) ? 4 : 16) : 0;
     constexpr int HY = SY == 2 ? 1 : 0;
     constexpr int PITCH = (CW + 2 * HX) / 4;             // dwords per LDS row
     constexpr int ROWS = CR + 2 * HY;
@@ -389,12 +393,28 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     const int nwaves = gridDim.x * NW;
     int s = a.first_tile + blockIdx.x * NW + wave;
     if (s >= a.total_tiles) return;
-    if constexpr (!DIRECT) dma_strip(s, lane0, INSTRIP ? 1 : 0);
+    // DIRECT: the block of the NEXT strip this work-item transforms, requested while the current one is worked on
+    uint32_t wn[DIRECT ? 32 : 1];
+    auto fetch_block = [&](int st, int ln) {
+        int im, sy_, sx_;
+        locate(st, im, sy_, sx_);
+        const int bx = min(sx_ * BX + (ln & (BX - 1)), a.ux - 1), by = min(BY * sy_ + (int)((unsigned)ln / BX), a.uy - 1);   // blocks outside the plane: pixels never stored
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.coef + im * a.coef_stride + ((size_t)by * a.ux + bx) * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 v = src[i];
+            wn[(4 * i + 0) % (DIRECT ? 32 : 1)] = v.x; wn[(4 * i + 1) % (DIRECT ? 32 : 1)] = v.y;
+            wn[(4 * i + 2) % (DIRECT ? 32 : 1)] = v.z; wn[(4 * i + 3) % (DIRECT ? 32 : 1)] = v.w;
+        }
+    };
+    if constexpr (DIRECT) fetch_block(s, lane0);
+    else dma_strip(s, lane0, INSTRIP ? 1 : 0);
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
 #ifdef JA_PHASE_PROFILE
     unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = __builtin_readcyclecounter();
+    const unsigned long long t_first = t_prev, r_first = __builtin_amdgcn_s_memrealtime();   // shader cycles / 100 MHz ticks
 #endif
 
     for (; s < a.total_tiles; s += nwaves) {
@@ -440,13 +460,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             }
         };
         if constexpr (DIRECT) {
-            const int bx = min(sxi * BX + lbx, a.ux - 1), by = min(BY * syi + seg, a.uy - 1);   // blocks outside the plane: pixels never stored
-            const uint4 *src = reinterpret_cast<const uint4 *>(a.coef + img * a.coef_stride + ((size_t)by * a.ux + bx) * 64);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint4 v = src[i];
-                w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-            }
+            for (int i = 0; i < 32; ++i) w[i] = wn[i % (DIRECT ? 32 : 1)];
         } else {
             read_block();
         }
@@ -627,7 +642,23 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             // rows of a narrow tile are packed RPI to a transfer (the LDS image is lane-linear and the
             // tile rows are contiguous): 12 transfers instead of 36 for a 16 x 4 strip of 4:2:0
             constexpr int RPI = (ROWS % (64 / PITCH) == 0) ? 64 / PITCH : 1;
-            if constexpr (RPI == 1) {
+            constexpr int CHUNKS = PITCH / 4;                 // 16-byte chunks per tile row
+            constexpr int SLOTS = 2 * ROWS * CHUNKS;          // both planes
+            if (PITCH % 4 == 0 && (a.pw_c & 15) == 0 && a.pw_c >= 16) {
+                // 16 bytes per lane: slot u = 64 i + lane is chunk u % CHUNKS of tile row u / CHUNKS (rows of both planes
+                // back to back); its LDS address is 16 u -- the tile rows are contiguous.  Chunks are clamped to the plane
+                // as a whole (the plane is a whole number of chunks wide here); what a clamped chunk holds is repaired below.
+#pragma unroll
+                for (int i = 0; i < (SLOTS + 63) / 64; ++i) {
+                    const int u = 64 * i + lane;
+                    const int r = (int)((unsigned)u / CHUNKS), ch = u - r * CHUNKS;
+                    const int pl = r >= ROWS ? 1 : 0;
+                    const int gy = min(max(cy0 - HY + r - pl * ROWS, 0), a.ph_c - 1);
+                    const int gx = min(max(cx0 - HX + 16 * ch, 0), a.pw_c - 16);
+                    const uint8_t *g = (pl ? a.cr : a.cb) + img * a.c_stride + ((size_t)gy * a.pw_c + gx);
+                    if (u < SLOTS) lds_dma16_keep(g, sc_lds + 1024 * i);
+                }
+            } else if constexpr (RPI == 1) {
                 const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + lane, 0), pwd - 1);
                 if (lane < PITCH) {
 #pragma unroll
@@ -678,13 +709,17 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         // ---- the chroma rows have landed (they are the only VM operations in flight) ----
         if constexpr (CHROMA && !INSTRIP) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int first_bad = pwd - (cx0 - HX) / 4;          // first column past the plane
+            const int first_bad = pwd - (cx0 - HX) / 4;          // first tile dword past the plane (>= HX / 4 + 1)
             if ((HX > 0 && sxi == 0) || first_bad < PITCH) {     // wave-uniform: edge strips only
-                // a clamped column must replicate the plane's first / last SAMPLE, not its dword
+                // the reference clamps the SAMPLE index to the padded plane (decode.swift:4245): whatever the clamped
+                // transfers put left of the first / right of the last sample is replaced by that sample
                 if (lane < 2 * ROWS) {
                     uint32_t *row = sc + lane * PITCH;
-                    if (HX > 0 && sxi == 0) row[0] = (row[0] & 0xffu) * 0x01010101u;
-                    for (int c = max(first_bad, 0); c < PITCH; ++c) row[c] = (row[c] >> 24) * 0x01010101u;
+                    if (HX > 0 && sxi == 0) row[HX / 4 - 1] = (row[HX / 4] & 0xffu) * 0x01010101u;
+                    if (first_bad < PITCH) {
+                        const uint32_t last = (row[first_bad - 1] >> 24) * 0x01010101u;
+                        for (int c = first_bad; c < PITCH; ++c) row[c] = last;
+                    }
                 }
             }
         }
@@ -707,7 +742,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         auto hraw = [&](int pl, int j, uint32_t (&r)[3]) {
             const uint32_t *row = sc + pl * PLANE + (seg * (8 / SY) + j) * PITCH;
             if constexpr (SX == 2) {
-                r[0] = row[lbx]; r[1] = row[lbx + 1]; r[2] = row[lbx + 2];
+                r[0] = row[HX / 4 - 1 + lbx]; r[1] = row[HX / 4 + lbx]; r[2] = row[HX / 4 + 1 + lbx];
             } else if constexpr (INTHREAD) {   // the block's own samples, parked above
                 r[0] = sc[(pl * 16 + 2 * j) * 64 + lane]; r[1] = sc[(pl * 16 + 2 * j + 1) * 64 + lane]; r[2] = 0;
             } else {
@@ -861,6 +896,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             //      this row (LDS ops of one wave execute in order) and read it back as chunks, request the chroma
             //      dwords of the next patch row ----
             if (y > 0) store_row(y - 1);
+            if constexpr (DIRECT) {
+                if (y == 4 && s + nwaves < a.total_tiles) fetch_block(s + nwaves, lane);
+            }
             uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
             sw[0] = make_uint2(d[0], d[1]);
             sw[1] = make_uint2(d[2], d[3]);
@@ -884,6 +922,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         JA_PHASE(5)
     }
 #ifdef JA_PHASE_PROFILE
+    // slots 6, 7: the wave's life in shader cycles and in ticks of the constant 100 MHz counter -> effective shader clock
+    phase_acc[6] = __builtin_readcyclecounter() - t_first;
+    phase_acc[7] = __builtin_amdgcn_s_memrealtime() - r_first;
     if (lane0 == 0 && blockIdx.x * NW + wave < 4096)
         for (int i = 0; i < 8; ++i) g_phase_cycles[(blockIdx.x * NW + wave) * 8 + i] = phase_acc[i];
 #endif

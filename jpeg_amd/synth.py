@@ -40,14 +40,17 @@ def natural_planes_torch(units, n_images: int, device, seed: int = SEED):
     for p, (ux, uy) in enumerate(units):
         g.manual_seed(seed + 7919 * p)
         out = torch.empty((n_images, uy, ux, 64), dtype=torch.int16, device=device)
-        # generate image by image to bound the float32 temporaries
-        for i in range(n_images):
-            u = torch.rand((uy, ux, 64), generator=g, device=device, dtype=torch.float32) - 0.5
+        # generate in groups of images that keep the float32 temporaries around 256 MiB
+        group = max(1, (1 << 26) // max(1, uy * ux * 64))
+        for i in range(0, n_images, group):
+            m = min(group, n_images - i)
+            u = torch.rand((m, uy, ux, 64), generator=g, device=device, dtype=torch.float32) - 0.5
             lap = -torch.sign(u) * torch.log1p(-2.0 * u.abs()).clamp_(min=-30.0)
             v = torch.round(lap * scale).clamp_(-2047, 2047).to(torch.int16)
-            v[..., 0] = torch.randint(-1024, 1024, (uy, ux), generator=g, device=device,
+            v[..., 0] = torch.randint(-1024, 1024, (m, uy, ux), generator=g, device=device,
                                       dtype=torch.int16)
-            out[i] = v
+            out[i:i + m] = v
+            del u, lap, v
         planes.append(out)
     return planes
 

@@ -49,6 +49,43 @@ def test_two_ranks_gloo(tmp_path):
     assert merged == want
 
 
+def test_bench_two_ranks_gloo(tmp_path):
+    """bench.py's own N > 1 path (bench.run) under gloo, world size 2, the oracle standing in for the kernels:
+    the default workload at N > 1 is ONE sharded C5 job (strong scaling), every image is decoded by exactly one
+    rank, the line carries a per-rank record, and `value` is all ranks' pixels over the slowest rank's time."""
+    world, n = 2, 5
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    outs = [str(tmp_path / f"bench{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_bench_worker.py"), str(r), str(world), str(port), outs[r], str(n)],
+                              stdout=subprocess.PIPE, text=True) for r in range(world)]
+    lines = []
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0
+        lines += [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    line = json.loads(lines[0])
+    recs = [json.load(open(o)) for o in outs]
+    assert recs[1]["result"] is None and recs[0]["result"] == line
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["steps"] == 2
+    assert line["config"]["images_per_step_all_ranks"] == n
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1]
+    assert sum(r["images_per_step"] for r in line["per_rank"]) == n
+    slowest = max(r["wall_ms_per_step"] for r in line["per_rank"])
+    assert abs(line["ms_per_step"] - slowest) < 1e-3 * slowest + 1e-3
+    px = W.SIZE[0] * W.SIZE[1] * n
+    assert abs(line["value"] - px / (line["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * line["value"] + 0.1
+    tables = W.tables()
+    images = W.images()
+    merged = {}
+    for r in recs:
+        assert not (set(merged) & set(r["digests"])), "an image was decoded by two ranks"
+        merged.update(r["digests"])
+    assert merged == {str(i): W.decode(images[i % W.N_IMAGES], tables) for i in range(n)}
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("size,factors", [((200, 333), [(2, 2), (1, 1), (1, 1)]), ((96, 64), [(2, 1), (1, 1), (1, 1)]),
                                            ((50, 90), [(1, 1), (1, 1), (1, 1)])])

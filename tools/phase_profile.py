@@ -33,3 +33,6 @@ print(f"step {ms*1e3:.1f} us; per-wave total cycles mean {tot.mean():.0f} min {t
 for i, n in enumerate(names):
     c = buf[:, i].astype(np.float64)
     print(f"  {n:40s} {c.mean():10.0f} cycles/wave  {100*c.mean()/tot.mean():5.1f} %   per strip {c.mean()/(16384/3072):8.0f}")
+life, ticks = buf[:, 6].astype(np.float64), buf[:, 7].astype(np.float64)
+print(f"wave life: mean {life.mean():.0f} max {life.max():.0f} shader cycles = mean {ticks.mean() / 100:.1f} max {ticks.max() / 100:.1f} us of the 100 MHz counter"
+      f" -> effective shader clock {100.0 * (life / ticks).mean():.0f} MHz while k_luma_fused runs")

@@ -209,6 +209,19 @@ typedef struct jpeg_amd_frame_info {
     int32_t nscans, restart_interval;
 } jpeg_amd_frame_info;
 
+/* JPEG.Table.Huffman<Symbol>.Decoder subscript  decode.swift:1243-1261 (table construction :1008-1240): build the
+ * decoder of a DHT table -- counts[l] codewords of length l + 1, `values` in codeword order -- and decode the
+ * codeword at the top of the 16-bit window `window` (big-endian, left-aligned).  A window that is no codeword gives
+ * symbol 0 and length 16: the reference renders damaged streams that way instead of failing, and so does
+ * jpeg_amd_jpeg_decode_spectral.  EINVAL for tables the reference's initialiser rejects (over-subscribed lengths,
+ * more than 256 values).  Known-answer vectors: tests/unit/tests.swift:141-461.  Host only. */
+int jpeg_amd_huffman_lookup(const uint8_t counts[16], const uint8_t *values, int nvalues,
+                            uint16_t window, int32_t *symbol, int32_t *length);
+/* JPEG.Table.Huffman<Symbol>.init(frequencies:target:)  encode.swift:597-760: the code Spectral.compress builds for
+ * a scan from its symbol frequencies (optimal lengths, the reference's tie-breaking and its 16-bit limiter), as a
+ * DHT table: counts[16], values[] in codeword order (*nvalues of them, <= 256).  freq[v] <= 0: symbol unused. */
+int jpeg_amd_huffman_build(const int64_t freq[256], uint8_t counts[16], uint8_t values[256], int32_t *nvalues);
+
 /* parse the headers (and walk the scans) without decoding: geometry for buffer allocation */
 int jpeg_amd_jpeg_inspect(const uint8_t *h_jpeg, size_t nbytes, jpeg_amd_frame_info *info);
 /* entropy-decode every scan into caller-allocated planes h_coef[c]: int16 [units_y][units_x][64]

@@ -76,6 +76,8 @@ SIGNATURES = {
     "jpeg_amd_host_rectangular_decomposed": (C.c_int, [_p, _L, _p, _pp]),
     "jpeg_amd_host_planar_fdct": (C.c_int, [_p, _L, _pp, _p, C.c_int, _pp]),
     "jpeg_amd_host_encode": (C.c_int, [_p, _L, _p, C.c_int, _p, C.c_int, _pp]),
+    "jpeg_amd_huffman_lookup": (C.c_int, [_p, _p, C.c_int, C.c_uint16, _p, _p]),
+    "jpeg_amd_huffman_build": (C.c_int, [_p, _p, _p, _p]),
     "jpeg_amd_jpeg_inspect": (C.c_int, [_p, C.c_size_t, _p]),
     "jpeg_amd_jpeg_decode_spectral": (C.c_int, [_p, C.c_size_t, _pp, _p, _p]),
     "jpeg_amd_jpeg_decode_spectral_mt": (C.c_int, [_p, C.c_size_t, _pp, _p, _p, C.c_int]),

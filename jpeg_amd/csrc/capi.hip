@@ -53,6 +53,12 @@ constexpr size_t kQSlotElems = JPEG_AMD_MAX_PLANES * 64;      // uint16 per slot
         }                                                         \
     } while (0)
 
+// Function-try-block tail of the entry points that allocate host memory or start threads: the header promises plain
+// C, so no C++ exception (std::bad_alloc, std::system_error from a thread that cannot be started) leaves the library.
+#define JA_NOTHROW_TAIL                                               \
+    catch (const std::bad_alloc &) { return JPEG_AMD_ENOMEM; }        \
+    catch (...) { return JPEG_AMD_ENOMEM; }
+
 #define JA_TRY(expr)                          \
     do {                                      \
         const int s_ = (expr);                \
@@ -96,8 +102,14 @@ int check_planes_cover_image(const jpeg_amd_layout *L)
                             (L->factor_x[p] == L->scale_x && L->factor_y[p] == L->scale_y);
         if (direct) {
             if (8 * L->units_x[p] < L->width || 8 * L->units_y[p] < L->height) return JPEG_AMD_EINVAL;
-        } else if (L->units_x[p] < 1 || L->units_y[p] < 1) {
-            return JPEG_AMD_EINVAL;
+        } else {
+            // bilinear: the sample index of the last pixel, i = (a + b (size - 1)) / c (decode.swift:4223-4246; its
+            // neighbour i + 1 is clamped to the plane, i itself is not), must lie inside the plane.  The cosited form
+            // i = factor (size - 1) / scale is the larger of the two.
+            if (L->units_x[p] < 1 || L->units_y[p] < 1) return JPEG_AMD_EINVAL;
+            const long long ix = (long long)L->factor_x[p] * (L->width - 1) / L->scale_x;
+            const long long iy = (long long)L->factor_y[p] * (L->height - 1) / L->scale_y;
+            if (ix >= 8LL * L->units_x[p] || iy >= 8LL * L->units_y[p]) return JPEG_AMD_EINVAL;
         }
     }
     return JPEG_AMD_OK;
@@ -620,7 +632,7 @@ size_t rect_samples(const jpeg_amd_layout *L) { return (size_t)L->width * L->hei
 int jpeg_amd_host_spectral_idct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
                                 const int16_t *const h_coef[], const uint16_t *h_quanta,
                                 int ntables, uint16_t *const h_planes[])
-{
+try {
     JA_TRY(bind(ctx));
     JA_TRY(check_layout(L, ntables));
     if (!h_coef || !h_planes) return JPEG_AMD_EINVAL;
@@ -638,11 +650,12 @@ int jpeg_amd_host_spectral_idct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 int jpeg_amd_host_planar_interleaved(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
                                      const uint16_t *const h_planes[], int cosited,
                                      uint16_t *h_rect)
-{
+try {
     JA_TRY(bind(ctx));
     JA_TRY(check_layout(L, -1));
     if (!h_planes || !h_rect) return JPEG_AMD_EINVAL;
@@ -657,10 +670,11 @@ int jpeg_amd_host_planar_interleaved(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 int jpeg_amd_host_rectangular_unpack(jpeg_amd_ctx *ctx, const uint16_t *h_rect, size_t npixels,
                                      int nplanes, jpeg_amd_color color, uint8_t *h_pixels)
-{
+try {
     JA_TRY(bind(ctx));
     if (nplanes != 1 && nplanes != 3) return JPEG_AMD_EINVAL;
     DeviceBag bag(ctx);
@@ -673,11 +687,12 @@ int jpeg_amd_host_rectangular_unpack(jpeg_amd_ctx *ctx, const uint16_t *h_rect, 
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 int jpeg_amd_host_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
                          const int16_t *const h_coef[], const uint16_t *h_quanta, int ntables,
                          int cosited, jpeg_amd_color color, uint8_t *h_pixels)
-{
+try {
     JA_TRY(bind(ctx));
     JA_TRY(check_layout(L, ntables));
     if (!h_coef || !h_pixels) return JPEG_AMD_EINVAL;
@@ -693,10 +708,11 @@ int jpeg_amd_host_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 int jpeg_amd_host_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *h_pixels, size_t npixels,
                                    int nplanes, jpeg_amd_color color, uint16_t *h_rect)
-{
+try {
     JA_TRY(bind(ctx));
     if (nplanes != 1 && nplanes != 3) return JPEG_AMD_EINVAL;
     DeviceBag bag(ctx);
@@ -709,10 +725,11 @@ int jpeg_amd_host_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *h_pixels, s
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 int jpeg_amd_host_rectangular_decomposed(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
                                          const uint16_t *h_rect, uint16_t *const h_planes[])
-{
+try {
     JA_TRY(bind(ctx));
     JA_TRY(check_layout(L, -1));
     if (!h_rect || !h_planes) return JPEG_AMD_EINVAL;
@@ -728,11 +745,12 @@ int jpeg_amd_host_rectangular_decomposed(jpeg_amd_ctx *ctx, const jpeg_amd_layou
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 int jpeg_amd_host_planar_fdct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
                               const uint16_t *const h_planes[], const uint16_t *h_quanta,
                               int ntables, int16_t *const h_coef[])
-{
+try {
     JA_TRY(bind(ctx));
     JA_TRY(check_layout(L, ntables));
     if (!h_coef || !h_planes) return JPEG_AMD_EINVAL;
@@ -750,11 +768,12 @@ int jpeg_amd_host_planar_fdct(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 int jpeg_amd_host_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const uint8_t *h_pixels,
                          jpeg_amd_color color, const uint16_t *h_quanta, int ntables,
                          int16_t *const h_coef[])
-{
+try {
     JA_TRY(bind(ctx));
     JA_TRY(check_layout(L, ntables));
     if (!h_coef || !h_pixels) return JPEG_AMD_EINVAL;
@@ -770,12 +789,13 @@ int jpeg_amd_host_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const uint
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 // ---- JPEG bytes -> pixels (host entropy decode + the fused device path) ----------------------
 int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes, int cosited,
                         jpeg_amd_color color, uint8_t *h_pixels, size_t pixel_capacity,
                         jpeg_amd_frame_info *info_out)
-{
+try {
     JA_TRY(bind(ctx));
     if (!h_jpeg) return JPEG_AMD_EINVAL;
     jpeg_amd_frame_info fi;
@@ -789,6 +809,7 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
     // host threads (their number left to the library)
     return jpeg_amd_decompress_batch(ctx, &h_jpeg, &nbytes, 1, 0, cosited, color, h_pixels, need, nullptr);
 }
+JA_NOTHROW_TAIL
 
 // ---- many JPEG files of one geometry -> pixels: host threads entropy-decode a chunk into
 //      pinned memory while the device (H2D, fused decode, D2H on the context's stream) works on
@@ -796,7 +817,7 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
 int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[],
                               int n_images, int nthreads, int cosited, jpeg_amd_color color,
                               uint8_t *h_pixels, size_t pixel_stride, jpeg_amd_frame_info *info_out)
-{
+try {
     JA_TRY(bind(ctx));
     if (!h_jpeg || !nbytes || !h_pixels || n_images < 0) return JPEG_AMD_EINVAL;
     if (n_images == 0) return JPEG_AMD_OK;
@@ -853,10 +874,18 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
 
 
     // run `fn(i)` for i in [0, m) on the pool (the calling thread takes a share)
+    // (fn does not throw; a worker that cannot be started leaves its share to the calling thread)
     auto parallel = [&](int m, auto &&fn) {
         const int t_n = std::min(nthreads, m);
         std::vector<std::thread> pool;
-        for (int t = 1; t < t_n; ++t) pool.emplace_back([&, t] { for (int i = t; i < m; i += t_n) fn(i); });
+        int started = 1;
+        try {
+            pool.reserve((size_t)t_n);
+            for (int t = 1; t < t_n; ++t) { pool.emplace_back([&, t] { for (int i = t; i < m; i += t_n) fn(i); }); ++started; }
+        } catch (...) {
+        }
+        for (int t = started; t < t_n; ++t)
+            for (int i = t; i < m; i += t_n) fn(i);
         for (int i = 0; i < m; i += t_n) fn(i);
         for (std::thread &th : pool) th.join();
     };
@@ -875,12 +904,17 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
         });
         return JPEG_AMD_OK;
     };
-    std::thread drainer;
+    struct Joining { std::thread t; ~Joining() { if (t.joinable()) t.join(); } } drainer_owner;   // joined on every way out
+    std::thread &drainer = drainer_owner.t;
     int drain_status = JPEG_AMD_OK;
     for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
         char *host = static_cast<char *>(ctx->file_pinned[slot]);
-        // slot `slot` was last used by chunk k - 2, which drain(k - 2) has already waited for
+        // Pinned slot `slot` was last used by chunk k - 2, whose uploads read its coefficient and table regions
+        // asynchronously: they are complete once that chunk's kernels are (file_decoded[slot] was recorded behind
+        // them).  The helper thread that copies chunk k - 2's pixels out of the same slot may still be running; it
+        // only reads the pixel region, which the decode below does not touch.
+        if (k >= 2) JA_HIP(ctx, hipEventSynchronize(ctx->file_decoded[slot]));
         std::vector<int> status((size_t)m, JPEG_AMD_OK);
         parallel(m, [&](int i) {
             int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
@@ -937,6 +971,7 @@ int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], 
     JA_TRY(drain(nchunks - 1));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 // ---- pixels -> JPEG bytes (the fused device path + host entropy encode) ----------------------
 int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels,
@@ -944,7 +979,7 @@ int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8
                       const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans,
                       int nscans, const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out, size_t capacity,
                       size_t *nbytes)
-{
+try {
     JA_TRY(bind(ctx));
     if (!frame || !h_pixels || !quanta_key || !h_quanta || !h_quanta_keys || !scans || !nbytes) return JPEG_AMD_EINVAL;
     const int nc = frame->ncomponents;
@@ -976,6 +1011,7 @@ int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8
     return jpeg_amd_jpeg_encode_spectral(frame, quanta_key, coef, h_quanta, h_quanta_keys, ntables, scans, nscans,
                                          metadata, nmetadata, h_out, capacity, nbytes);
 }
+JA_NOTHROW_TAIL
 
 // ---- many pictures of one geometry -> JPEG files: one fused encode launch per chunk, the host
 //      threads entropy-code the planes of a chunk as soon as they are back ------------------------
@@ -985,7 +1021,7 @@ int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const
                             int ntables, const jpeg_amd_scan *scans, int nscans,
                             const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
                             uint8_t *h_out, size_t out_stride, size_t nbytes[])
-{
+try {
     JA_TRY(bind(ctx));
     if (!frame || !h_pixels || !quanta_key || !h_quanta || !h_quanta_keys || !scans || !h_out || !nbytes || n_images < 0)
         return JPEG_AMD_EINVAL;
@@ -1055,8 +1091,15 @@ int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const
                                                           &nbytes[base + i]);
             }
         };
+        // a worker that cannot be started leaves its share to the calling thread (work does not throw)
         std::vector<std::thread> pool;
-        for (int t = 1; t < nthreads; ++t) pool.emplace_back(work, t);
+        int started = 1;
+        try {
+            pool.reserve((size_t)nthreads);
+            for (int t = 1; t < nthreads; ++t) { pool.emplace_back(work, t); ++started; }
+        } catch (...) {
+        }
+        for (int t = started; t < nthreads; ++t) work(t);
         work(0);
         for (std::thread &th : pool) th.join();
         for (int st : status) if (st != JPEG_AMD_OK) return st;   // EINVAL with nbytes[i] > out_stride: buffer too small
@@ -1079,5 +1122,6 @@ int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const
     JA_TRY(entropy_code(nchunks - 1));
     return JPEG_AMD_OK;
 }
+JA_NOTHROW_TAIL
 
 }  // extern "C"

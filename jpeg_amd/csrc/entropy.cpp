@@ -36,8 +36,36 @@ struct Huffman {
     int16_t fast_ac[512];
     bool defined = false;
 
+    // Decoder subscript of the reference (decode.swift:1243-1261): the symbol and length of the codeword at the top
+    // of a 16-bit window.  A window that matches no codeword decodes as SYMBOL 0 OF LENGTH 16 -- the reference
+    // renders damaged streams that way instead of failing (tests/unit/tests.swift:424-430), and so does this decoder.
+    inline int lookup(uint16_t window, int &len) const
+    {
+        const uint16_t f = fast[window >> 7];
+        if (f) { len = f >> 8; return f & 0xff; }
+        for (len = 10; len <= 16; ++len) {
+            const int code = window >> (16 - len);
+            if (code <= maxcode[len]) {
+                if (code < mincode[len]) break;          // below the first code of this length: not a codeword
+                return symbols[valptr[len] + code - mincode[len]];
+            }
+        }
+        len = 16;
+        return 0;
+    }
+
+    // Builds into a temporary and commits only on success: a malformed DHT leaves the previous table intact.
     bool build(const uint8_t counts[16], const uint8_t *syms, int nsyms)
     {
+        Huffman t;
+        if (!t.build_in_place(counts, syms, nsyms)) return false;
+        *this = t;
+        return true;
+    }
+
+    bool build_in_place(const uint8_t counts[16], const uint8_t *syms, int nsyms)
+    {
+        if (nsyms < 0 || nsyms > 256) return false;
         std::memset(fast, 0, sizeof fast);
         std::memcpy(symbols, syms, (size_t)nsyms);
         int code = 0, k = 0;
@@ -124,11 +152,10 @@ struct BitReader {
         if (nbits < 16) refill();
         const uint16_t f = h.fast[peek(9)];
         if (f) { skip(f >> 8); return f & 0xff; }
-        int code = (int)peek(10), len = 10;
-        while (len <= 16 && code > h.maxcode[len]) { ++len; code = (int)peek(len); }
-        if (len > 16) { skip(16); return -1; }
+        int len;
+        const int sym = h.lookup((uint16_t)peek(16), len);
         skip(len);
-        return h.symbols[h.valptr[len] + code - h.mincode[len]];
+        return sym;
     }
     // at a restart boundary: drop the padding bits and position on the byte after RSTn
     // (refill never reads past a marker, so everything buffered belongs to the old interval)
@@ -204,11 +231,17 @@ struct Decoder {
         if (t_n < 2) { std::memset(p, 0, bytes); return; }
         std::vector<std::thread> pool;
         const size_t per = (bytes / t_n + 63) & ~(size_t)63;
-        for (int t = 0; t < t_n; ++t)
-            pool.emplace_back([=] {
-                const size_t lo = std::min(bytes, per * t), hi = t + 1 == t_n ? bytes : std::min(bytes, per * (t + 1));
-                std::memset(reinterpret_cast<char *>(p) + lo, 0, hi - lo);
-            });
+        auto clear = [=](int t) {
+            const size_t lo = std::min(bytes, per * t), hi = t + 1 == t_n ? bytes : std::min(bytes, per * (t + 1));
+            std::memset(reinterpret_cast<char *>(p) + lo, 0, hi - lo);
+        };
+        int started = 0;   // a thread that cannot be started leaves its piece to this one; nothing is left joinable
+        try {
+            pool.reserve((size_t)t_n);
+            for (int t = 0; t < t_n; ++t) { pool.emplace_back(clear, t); ++started; }
+        } catch (...) {
+        }
+        for (int t = started; t < t_n; ++t) clear(t);
         for (std::thread &th : pool) th.join();
     }
 
@@ -471,7 +504,13 @@ struct Decoder {
                     }
                 };
                 std::vector<std::thread> pool;
-                for (int t = 1; t < t_n; ++t) pool.emplace_back(work, t);
+                int started = 1;
+                try {
+                    pool.reserve((size_t)t_n);
+                    for (int t = 1; t < t_n; ++t) { pool.emplace_back(work, t); ++started; }
+                } catch (...) {
+                }
+                for (int t = started; t < t_n; ++t) work(t);
                 work(0);
                 for (std::thread &th : pool) th.join();
                 for (int st : status) if (st != JPEG_AMD_OK) return st;
@@ -493,6 +532,8 @@ struct Decoder {
     // segment that is not complete yet -- JPEG.Context fed by a growing byte stream
     // (decode.swift:3554-3961, examples/decode-online); `finished` is set at EOI.
     size_t pos = 0;
+    size_t scan_search_segment = (size_t)-1, scan_search_from = 0;   // streaming: where the hunt for a scan's end stopped
+    static constexpr long long kStreamMaxBlocks = 1LL << 25;
     bool have_frame = false, streaming = false, finished = false;
     std::vector<std::vector<int16_t>> own_planes;       // streaming: the decoder owns the planes
     uint16_t own_quanta[JPEG_AMD_MAX_PLANES][64];
@@ -531,7 +572,17 @@ struct Decoder {
                         goto out_of_data;
                     }
                     st = parse_sof(marker, seg, len);
+                    if (st == JPEG_AMD_OK)
+                        for (int c = 0; c < info.ncomponents; ++c)     // the bound the device ABI puts on a plane (check_layout)
+                            if ((long long)comps[c].ux * comps[c].uy > (1LL << 30)) return JPEG_AMD_EINVAL;
                     if (st == JPEG_AMD_OK && streaming) {
+                        // the stream decoder OWNS the planes: an attacker-chosen frame size must not make it allocate
+                        // tens of gigabytes from a 20-byte header.  32 Mi blocks (4 GiB of coefficients, e.g. a 4:2:0
+                        // image of 37 000 x 37 000) is the cap; larger frames go through the one-shot entry points,
+                        // where the caller allocates.
+                        long long blocks = 0;
+                        for (int c = 0; c < info.ncomponents; ++c) blocks += (long long)comps[c].ux * comps[c].uy;
+                        if (blocks > kStreamMaxBlocks) return JPEG_AMD_ENOMEM;
                         have_frame = true;
                         own_planes.assign((size_t)info.ncomponents, {});
                         for (int c = 0; c < info.ncomponents; ++c) {
@@ -560,8 +611,9 @@ struct Decoder {
                     break;
                 case 0xda: {
                     if (!have_frame) return JPEG_AMD_EINVAL;
-                    // entropy-coded data runs to the next marker that is not RSTn / stuffing
-                    size_t e = pos;
+                    // entropy-coded data runs to the next marker that is not RSTn / stuffing.  A streaming decoder that
+                    // comes back to the same scan with more bytes resumes the search where the last one gave up.
+                    size_t e = (streaming && scan_search_segment == segment_start && scan_search_from > pos) ? scan_search_from : pos;
                     while (e + 1 < n) {
                         const void *ff = std::memchr(data + e, 0xff, n - 1 - e);
                         if (!ff) { e = n; break; }
@@ -572,7 +624,12 @@ struct Decoder {
                         break;
                     }
                     if (e + 1 >= n) {
-                        if (streaming) { pos = segment_start; goto out_of_data; }   // the scan's end is not here yet
+                        if (streaming) {                                            // the scan's end is not here yet
+                            scan_search_segment = segment_start;
+                            scan_search_from = n > 0 ? n - 1 : 0;                   // the last byte may be half of a marker
+                            pos = segment_start;
+                            goto out_of_data;
+                        }
                         e = n;
                     }
                     st = decode_scan(seg, len, data + pos, data + e, streaming ? own_quanta : quanta_out);
@@ -597,14 +654,38 @@ struct Decoder {
 
 extern "C" {
 
+int jpeg_amd_huffman_lookup(const uint8_t counts[16], const uint8_t *values, int nvalues,
+                            uint16_t window, int32_t *symbol, int32_t *length)
+{
+    if (!counts || (!values && nvalues > 0) || !symbol || !length || nvalues < 0 || nvalues > 256) return JPEG_AMD_EINVAL;
+    int total = 0;
+    for (int l = 0; l < 16; ++l) total += counts[l];
+    if (total != nvalues) return JPEG_AMD_EINVAL;
+    Huffman h;
+    if (!h.build(counts, values, nvalues)) return JPEG_AMD_EINVAL;
+    int len = 0;
+    *symbol = h.lookup(window, len);
+    *length = len;
+    return JPEG_AMD_OK;
+}
+
+// The header promises plain C: no C++ exception (std::bad_alloc from a vector, std::system_error from a thread that
+// cannot be started) may leave an entry point.
+#define JA_NOTHROW_BEGIN try {
+#define JA_NOTHROW_END                                      \
+    } catch (const std::bad_alloc &) { return JPEG_AMD_ENOMEM; } \
+    catch (...) { return JPEG_AMD_ENOMEM; }
+
 int jpeg_amd_jpeg_inspect(const uint8_t *data, size_t nbytes, jpeg_amd_frame_info *info)
 {
     if (!data || !info) return JPEG_AMD_EINVAL;
+    JA_NOTHROW_BEGIN
     Decoder d{data, nbytes};
     const int st = d.run(nullptr, nullptr);
     if (st != JPEG_AMD_OK) return st;
     *info = d.info;
     return JPEG_AMD_OK;
+    JA_NOTHROW_END
 }
 
 int jpeg_amd_jpeg_decode_spectral(const uint8_t *data, size_t nbytes, int16_t *const h_coef[],
@@ -624,6 +705,7 @@ int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *data, size_t nbytes, in
                                           int max_scans)
 {
     if (!data || !h_coef || !h_quanta || max_scans < 0) return JPEG_AMD_EINVAL;
+    JA_NOTHROW_BEGIN
     Decoder d{data, nbytes};
     d.nthreads = nthreads > 0 ? nthreads : (int)std::max(1u, std::thread::hardware_concurrency());
     d.auto_threads = nthreads <= 0;
@@ -639,12 +721,14 @@ int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *data, size_t nbytes, in
         if (!c.bound && max_scans == 0) return JPEG_AMD_EINVAL;   // a component no scan ever touched
     if (info) *info = d.info;
     return JPEG_AMD_OK;
+    JA_NOTHROW_END
 }
 
 // ---- a decoder fed by a growing byte stream (JPEG.Context, examples/decode-online) ------------
 struct jpeg_amd_stream {
     std::vector<uint8_t> bytes;
     Decoder dec{nullptr, 0};
+    int failed = JPEG_AMD_OK;   // the first error is final: a decoder that has seen a malformed segment is not fed again
 };
 
 jpeg_amd_stream *jpeg_amd_stream_create(void)
@@ -659,10 +743,19 @@ void jpeg_amd_stream_destroy(jpeg_amd_stream *s) { delete s; }
 int jpeg_amd_stream_push(jpeg_amd_stream *s, const uint8_t *h_bytes, size_t nbytes, int *scans_done, int *finished)
 {
     if (!s || (nbytes && !h_bytes)) return JPEG_AMD_EINVAL;
-    s->bytes.insert(s->bytes.end(), h_bytes, h_bytes + nbytes);
-    s->dec.data = s->bytes.data();               // the buffer may have moved: the decoder keeps offsets only
-    s->dec.n = s->bytes.size();
-    const int st = s->dec.run(nullptr, nullptr);
+    if (s->failed != JPEG_AMD_OK) return s->failed;
+    int st = JPEG_AMD_OK;
+    try {
+        s->bytes.insert(s->bytes.end(), h_bytes, h_bytes + nbytes);
+        s->dec.data = s->bytes.data();               // the buffer may have moved: the decoder keeps offsets only
+        s->dec.n = s->bytes.size();
+        st = s->dec.run(nullptr, nullptr);
+    } catch (const std::bad_alloc &) {
+        st = JPEG_AMD_ENOMEM;
+    } catch (...) {
+        st = JPEG_AMD_ENOMEM;
+    }
+    if (st != JPEG_AMD_OK) s->failed = st;
     if (scans_done) *scans_done = s->dec.nscans;
     if (finished) *finished = s->dec.finished ? 1 : 0;
     return st;

@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/jpeg_amd.h"
@@ -491,13 +492,32 @@ int progressive_scan(std::vector<uint8_t> &out, const jpeg_amd_scan &sc, const s
 
 }  // namespace
 
+extern "C" int jpeg_amd_huffman_build(const int64_t freq[256], uint8_t counts[16], uint8_t values[256], int32_t *nvalues)
+{
+    if (!freq || !counts || !values || !nvalues) return JPEG_AMD_EINVAL;
+    try {
+        long f[256];
+        for (int v = 0; v < 256; ++v) f[v] = (long)freq[v];
+        Codebook cb;
+        if (!build_codebook(f, cb)) return JPEG_AMD_EINVAL;
+        std::memcpy(counts, cb.counts, 16);
+        std::memcpy(values, cb.symbols.data(), cb.symbols.size());
+        *nvalues = (int32_t)cb.symbols.size();
+        return JPEG_AMD_OK;
+    } catch (const std::bad_alloc &) {
+        return JPEG_AMD_ENOMEM;
+    } catch (...) {
+        return JPEG_AMD_EINVAL;
+    }
+}
+
 extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_t *quanta_key,
                                              const int16_t *const h_coef[], const uint16_t *h_quanta,
                                              const int32_t *h_quanta_keys, int ntables,
                                              const jpeg_amd_scan *scans, int nscans,
                                              const jpeg_amd_metadata *metadata, int nmetadata,
                                              uint8_t *h_out, size_t capacity, size_t *nbytes)
-{
+try {
     if (!frame || !quanta_key || !h_coef || !h_quanta || !h_quanta_keys || !scans || !nbytes) return JPEG_AMD_EINVAL;
     const int nc = frame->ncomponents;
     if (nc < 1 || nc > JPEG_AMD_MAX_PLANES || nscans < 1 || ntables < 1) return JPEG_AMD_EINVAL;
@@ -718,3 +738,5 @@ extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, c
     std::memcpy(h_out, out.data(), out.size());
     return JPEG_AMD_OK;
 }
+catch (const std::bad_alloc &) { return JPEG_AMD_ENOMEM; }
+catch (...) { return JPEG_AMD_ENOMEM; }

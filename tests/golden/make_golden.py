@@ -33,6 +33,43 @@ from oracle import jpeg_reader as R  # noqa: E402
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 
 
+def huffman_unit_vectors(ref):
+    """The known-answer vectors of tests/unit/tests.swift:141-461 as data: the Annex-K AC table (counts, values) with the
+    162 (length, codeword) pairs the test walks in symbol order, and the three hand-made trees with their bit streams
+    and expected symbols (the third one contains windows that are no codeword: symbol 0, 16 bits)."""
+    import re
+    text = open(os.path.join(ref, "tests", "unit", "tests.swift")).read()
+    body = text[text.index("func huffmanBuilding()"):text.index("func huffmanCoding()")]
+    counts = [int(x, 16) for x in re.findall(r"0x([0-9A-Fa-f]{2})", body[body.index("let counts"):body.index("let values")])]
+    values = [int(x, 16) for x in re.findall(r"0x([0-9A-Fa-f]{2})", body[body.index("let values"):body.index("guard let table")])]
+    pairs = [[int(l), int(c, 2)] for l, c in re.findall(r"\((\d+),\s*0b([01]+)\)", body)]
+    assert len(counts) == 16 and sum(counts) == len(values) == 162 and len(pairs) == 162
+    # expected symbols, as the test's loop generates them
+    expected, e = [], 0
+    for _ in pairs:
+        expected.append(e)
+        if e & 0x0f < 0x0a:
+            e = (e & 0xf0) | ((e & 0x0f) + 1)
+        else:
+            e = (((e & 0xf0) + 0x10) & 0xff) | (0 if e & 0xf0 == 0xe0 else 1)
+    coding = text[text.index("func huffmanCoding()"):text.index("func huffmanCodingSymmetric")]
+    trees_src = coding[coding.index("let trees"):coding.index("let pairs")]
+    trees = []
+    for block in re.findall(r"\[\s*\n((?:\s*(?://[^\n]*\n|\[[^\]]*\],?\s*)+))\s*\],", trees_src):
+        levels = [[int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{2})", lv)] for lv in re.findall(r"\[([^\[\]]*)\]", block)]
+        if len(levels) == 16:
+            trees.append(levels)
+    pairs_src = coding[coding.index("let pairs"):coding.index("for (symbols")]
+    streams = []
+    for enc, dec in re.findall(r"\(\s*(?://[^\n]*\n\s*)*\[([^\]]*)\]\s*,\s*\[([^\]]*)\]\s*\)", pairs_src):
+        bits = "".join(re.findall(r"[01_]+", "".join(re.findall(r"0b([01_]+)", enc)))).replace("_", "")
+        streams.append({"bits": bits, "symbols": [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{2})", dec)]})
+    assert len(trees) == 3 and len(streams) == 3, (len(trees), len(streams))
+    return {"source": "tests/unit/tests.swift:141-461 (huffmanBuilding, huffmanCoding)",
+            "annex_k_ac": {"counts": counts, "values": values, "codewords": pairs, "symbols": expected},
+            "coding": [{"levels": t, **st} for t, st in zip(trees, streams)]}
+
+
 def sha(b) -> str:
     return hashlib.sha256(bytes(b)).hexdigest()
 
@@ -196,5 +233,12 @@ def main():
     print("wrote", os.path.join(HERE, "MANIFEST.json"))
 
 
+def write_huffman_unit():
+    out = os.path.join(HERE, "huffman_unit.json")
+    json.dump(huffman_unit_vectors(REF), open(out, "w"), indent=1)
+    print("wrote", out)
+
+
 if __name__ == "__main__":
+    write_huffman_unit()
     main()

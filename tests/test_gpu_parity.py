@@ -241,6 +241,14 @@ def test_precondition_failures_come_back_as_einval(J, ctx):
     L = layout.c_layout((0, 8))
     st = _lib.lib().jpeg_amd_planar_interleaved(ctx.handle, C.byref(L), _lib.ptr_array([1, 1, 1]), 0, 1)
     assert st == _lib.EINVAL                   # decode.swift:2599 size must be positive
+    # subsampled planes too small for the image: the bilinear sample index of the last pixel would fall outside the
+    # plane (the reference traps on the array access, decode.swift:4243-4257); EINVAL here, never an out-of-bounds read
+    sub = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 0), 3: J.Component((1, 1), 0)})
+    L = sub.c_layout((64, 64), [(8, 8), (1, 1), (1, 1)], [0, 0, 0])   # chroma planes of 8 x 8 samples for 64 x 64 pixels
+    st = _lib.lib().jpeg_amd_planar_interleaved(ctx.handle, C.byref(L), _lib.ptr_array([1, 1, 1]), 0, 1)
+    assert st == _lib.EINVAL
+    st = _lib.lib().jpeg_amd_planar_interleaved(ctx.handle, C.byref(L), _lib.ptr_array([1, 1, 1]), 1, 1)
+    assert st == _lib.EINVAL
 
 
 def test_host_buffer_abi(J, ctx):

@@ -342,3 +342,114 @@ def test_fused_kernels_on_random_geometry(J, ctx, case):
     enc = [O.fdct_plane(p, quanta[i]) for p, i in zip(planar, q)]
     for a, b in zip(coef, enc):
         assert (a == b).all(), "encode differs"
+
+
+# ---- f-4: generic JPEG.Format plug-ins -- parity-unpinned: the reference holds no gold for 12 / 16-bit,
+# ---- 4-plane or cosited data (examples/custom-color only writes a JPEG), so the oracle is the only checker here -----
+
+@pytest.mark.parametrize("precision", [12, 16])
+@pytest.mark.parametrize("nplanes", [1, 3, 4])
+def test_generic_format_decode_and_encode_parity_unpinned_no_reference_gold(J, ctx, precision, nplanes):
+    """Spectral.idct / Planar.interleaved (centred and cosited) and Rectangular.decomposed / Planar.fdct for custom
+    formats of 12 and 16 bits: decode.swift:4101-4133 with level 2^(P-1) + 0.5 and clamp to 2^P - 1, and
+    encode.swift:80-99 where load() clamps samples ABOVE the format's limit (min(limit, sample)) -- the samples fed
+    to the encoder here exceed it on purpose."""
+    rng = np.random.default_rng(1000 * precision + nplanes)
+    factors = [(2, 2), (1, 1), (1, 2), (2, 1)][:nplanes] if nplanes > 1 else [(1, 1)]
+    size = (61, 45)
+    layout = J.Layout(("custom", precision, nplanes), {i + 1: J.Component(f, i & 1) for i, f in enumerate(factors)})
+    units = layout.units(size)
+    amp = 1 << (precision - 1)
+    planes = []
+    for ux, uy in units:
+        c = rng.integers(-amp, amp, (uy, ux, 64)).astype(np.int32)
+        c[..., 5:] //= 32
+        planes.append(np.clip(c, -32768, 32767).astype(np.int16))
+    tables = [rng.integers(1, 12, 64).astype(np.uint16) for _ in range(2)]
+    q = [c.qi for c in layout.planes]
+    spectral = J.Spectral.from_host(ctx, size, layout, planes, tables, q=q)
+    planar = spectral.idct()
+    want_p = [O.idct_plane(p, tables[i], precision) for p, i in zip(planes, q)]
+    for got, want in zip(planar.host_planes(), want_p):
+        assert (got == want).all()
+    assert max(int(w.max()) for w in want_p) == (1 << precision) - 1      # the clamp at 2^P - 1 is exercised
+    fs = [c.factor for c in layout.planes]
+    for cosite in (False, True):
+        rect = planar.interleaved(cosite=cosite).host_values()
+        assert (rect == O.interleave(want_p, fs, layout.scale, size, cosited=cosite)).all()
+    # encode: samples over the whole uint16 range, i.e. above the limit for P = 12
+    samples = rng.integers(0, 65536, (size[1], size[0], nplanes)).astype(np.uint16)
+    back = J.Rectangular.from_host(ctx, size, layout, samples).decomposed()
+    want_d = O.decompose(samples, size, fs, layout.scale)
+    for got, want in zip(back.host_planes(), want_d):
+        assert (got == want).all()
+    # (quanta >= 16: with random 16-bit samples smaller divisors would push coefficients past Int16, where the
+    # reference traps)
+    enc_tables = [rng.integers(16, 60, 64).astype(np.uint16) for _ in range(2)]
+    sp2 = back.fdct({i: enc_tables[i] for i in range(2)})
+    want_f = [O.fdct_plane(p, enc_tables[c.qi], precision) for p, c in zip(want_d, layout.planes)]
+    assert max(int(np.abs(w.astype(np.int32)).max()) for w in want_f) < 32000
+    for got, want in zip(sp2.host_planes(), want_f):
+        assert (got == want).all()
+    if precision == 12:
+        over = [O.fdct_plane(np.minimum(p, 4095), enc_tables[c.qi], precision) for p, c in zip(want_d, layout.planes)]
+        assert all((a == b).all() for a, b in zip(want_f, over)), "oracle: load(limit:) clamps at 2^P - 1"
+        assert any((p > 4095).any() for p in want_d)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_generic_format_seeded_sweep_parity_unpinned_no_reference_gold(J, ctx, seed):
+    """Ten random formats per seed (1-4 planes, factors 1-4, 8 / 12 / 16 bits, centred or cosited) through the staged
+    kernels both ways -- the collected share of tests/soak_staged.py."""
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(10):
+        n = int(rng.integers(1, 5))
+        precision = int(rng.choice([8, 12, 16]))
+        w, h = int(rng.integers(1, 120)), int(rng.integers(1, 90))
+        comps = {i + 1: J.Component((int(rng.integers(1, 5)), int(rng.integers(1, 5))), int(rng.integers(0, 2))) for i in range(n)}
+        layout = J.Layout(("custom", precision, n), comps)
+        units = layout.units((w, h))
+        amp = 1 << (precision + 1)
+        planes = []
+        for ux, uy in units:
+            c = rng.integers(-amp, amp, (uy, ux, 64)).astype(np.int32)
+            c[..., 6:] //= 16
+            planes.append(np.clip(c, -32768, 32767).astype(np.int16))
+        quanta = [rng.integers(1, 50, 64).astype(np.uint16) for _ in range(2)]
+        q = [c.qi for c in layout.planes]
+        keys = sorted(set(q)); q = [keys.index(k) for k in q]; tables = [quanta[k] for k in keys]
+        cosite = bool(rng.integers(2))
+        tag = (w, h, n, precision, cosite, [c.factor for c in layout.planes])
+        planar = J.Spectral.from_host(ctx, (w, h), layout, planes, tables, q=q).idct()
+        want_p = [O.idct_plane(p, tables[i], precision) for p, i in zip(planes, q)]
+        assert all((a == b).all() for a, b in zip(planar.host_planes(), want_p)), tag
+        factors = [c.factor for c in layout.planes]
+        want_r = O.interleave(want_p, factors, layout.scale, (w, h), cosited=cosite)
+        assert (planar.interleaved(cosite=cosite).host_values() == want_r).all(), tag
+        back = J.Rectangular.from_host(ctx, (w, h), layout, want_r).decomposed()
+        want_d = O.decompose(want_r.reshape(h, w, n), (w, h), factors, layout.scale)
+        assert all((a == b).all() for a, b in zip(back.host_planes(), want_d)), tag
+        sp2 = back.fdct({c.qi: quanta[c.qi] for c in layout.planes})
+        want_f = [O.fdct_plane(p, quanta[c.qi], precision) for p, c in zip(want_d, layout.planes)]
+        assert all((a == b).all() for a, b in zip(sp2.host_planes(), want_f)), tag
+
+
+@pytest.mark.parametrize("sampling", [[(2, 2), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)], [(1, 1), (1, 1), (1, 1)]])
+def test_cosited_through_the_fused_entry_point_parity_unpinned_no_reference_gold(J, ctx, sampling):
+    """jpeg_amd_decode(cosited = 1) on the built-in ycc8 format: the fused kernels only implement centred upsampling,
+    so the call must take the staged kernels and still agree with Planar.interleaved(cosite: true)
+    (decode.swift:4223-4230) + unpack.  The reference has no cosited gold."""
+    rng = np.random.default_rng(31)
+    size = (203, 97)
+    layout = J.Layout("ycc8", {i + 1: J.Component(f, min(i, 1)) for i, f in enumerate(sampling)})
+    units = layout.units(size)
+    planes = [np.clip(rng.laplace(0, 40, (uy, ux, 64)), -1000, 1000).astype(np.int16) for ux, uy in units]
+    tables = [rng.integers(1, 20, 64).astype(np.uint16) for _ in range(2)]
+    q = [c.qi for c in layout.planes]
+    spectral = J.Spectral.from_host(ctx, size, layout, planes, tables, q=q)
+    want_p = [O.idct_plane(p, tables[i], 8) for p, i in zip(planes, q)]
+    fs = [c.factor for c in layout.planes]
+    for cosite in (True, False):
+        rect = O.interleave(want_p, fs, layout.scale, size, cosited=cosite)
+        assert (spectral.decode(J.RGB, cosite=cosite).cpu().numpy() == O.unpack_rgb8(rect, 3)).all()
+        assert (spectral.decode(J.YCbCr, cosite=cosite).cpu().numpy() == O.unpack_ycc8(rect, 3)).all()

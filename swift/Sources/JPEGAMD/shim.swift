@@ -1,33 +1,64 @@
-// shim.swift -- drop-in replacements for the six hot-path methods of tayloraswift/jpeg
-// (reference @ 2024_08_07) on top of libjpeg_amd.so.  Logic-free by design: every method
-// marshals the reference's own containers into the C ABI (include/jpeg_amd.h) and back.
+// shim.swift -- drop-in replacements for the hot-path methods of tayloraswift/jpeg (reference @ 2024_08_07) on top
+// of libjpeg_amd.so.  Logic-free by design: every method marshals the reference's own containers into the C ABI
+// (include/jpeg_amd.h) and back.
 //
-// NOT compile-checked: the build image has no Swift toolchain (see INTEGRATION.md).
-// Must be compiled INSIDE the JPEG module (a fork / local package override), because it
-// reads `Spectral.Plane.buffer`, `Planar.Plane.buffer` and `Rectangular.values`, which the
-// reference declares private / internal (decode.swift:1433-1434, 1575-1576, 1673).
+// NOT compile-checked: the build image has no Swift toolchain (see INTEGRATION.md).  It is written to be compiled
+// INSIDE the JPEG module -- swift/patches/apply_2024_08_07.py copies it into sources/jpeg/, removes the four method
+// bodies it replaces and the two `private`s in front of `Spectral.Plane.buffer` / `Planar.Plane.buffer`
+// (decode.swift:1433, 1575), and swift/patches/Package.swift.overlay adds the C target.
 //
-//   replaces                                   reference
-//   Spectral.idct()                            decode.swift:4154-4165
-//   Planar.interleaved(cosite:)                decode.swift:4182-4276
-//   Rectangular.unpack(as:)  [YCbCr, RGB]      decode.swift:4291-4298
-//   Rectangular.pack(size:layout:metadata:pixels:)   encode.swift:453-464
-//   Rectangular.decomposed()                   encode.swift:389-425
-//   Planar.fdct(quanta:)                       encode.swift:353-370
+//   replaces (the reference's definition is deleted)      reference
+//   Spectral.idct()                                       decode.swift:4153-4165
+//   Planar.interleaved(cosite:)                           decode.swift:4181-4276
+//   Planar.fdct(quanta:)                                  encode.swift:352-370
+//   Rectangular.decomposed()                              encode.swift:388-425
+//   overloads (the reference's generic definition stays for every other JPEG.Color conformance)
+//   Rectangular.unpack(as:)  for JPEG.RGB / JPEG.YCbCr    decode.swift:4291-4298
+//   Rectangular.pack(size:layout:metadata:pixels:)  same  encode.swift:453-464
+//
+// Memory rules kept throughout: no pointer obtained from a `withUnsafe...` closure is used after that closure has
+// returned (arrays of arrays go through the recursive helpers below, which keep every scope open across the C call),
+// and pixel arrays cross the boundary as raw bytes, never element by element.
 
 import CJPEGAMD
+#if canImport(Glibc)
+import Glibc
+#elseif canImport(Darwin)
+import Darwin
+#endif
 
-/// One context per thread; the hot path is a pure function of its inputs in the reference,
-/// so a lazily created per-thread context keeps that contract.
 enum AMD
 {
-    static let context:OpaquePointer =
+    /// A jpeg_amd_ctx is single-threaded (include/jpeg_amd.h), while the methods replaced here are pure functions of
+    /// value types that callers may run on several threads at once: contexts are borrowed from a pool for the
+    /// duration of one call (created on demand, returned afterwards), never shared between two running calls.
+    private final
+    class Pool
     {
-        var ctx:OpaquePointer? = nil
-        let status:Int32 = jpeg_amd_ctx_create(0, nil, JPEG_AMD_CTX_OWN_STREAM, &ctx)
-        precondition(status == 0, "jpeg_amd_ctx_create: \(String(cString: jpeg_amd_strerror(status)))")
-        return ctx!
-    }()
+        var lock:pthread_mutex_t = .init()
+        var free:[OpaquePointer] = []
+        init() { pthread_mutex_init(&self.lock, nil) }
+    }
+    private static let pool:Pool = .init()
+
+    static func withContext<R>(_ body:(OpaquePointer) -> R) -> R
+    {
+        pthread_mutex_lock(&Self.pool.lock)
+        var ctx:OpaquePointer? = Self.pool.free.popLast()
+        pthread_mutex_unlock(&Self.pool.lock)
+        if ctx == nil
+        {
+            let status:Int32 = jpeg_amd_ctx_create(0, nil, JPEG_AMD_CTX_OWN_STREAM, &ctx)
+            precondition(status == 0, "jpeg_amd_ctx_create: \(String(cString: jpeg_amd_strerror(status)))")
+        }
+        defer
+        {
+            pthread_mutex_lock(&Self.pool.lock)
+            Self.pool.free.append(ctx!)
+            pthread_mutex_unlock(&Self.pool.lock)
+        }
+        return body(ctx!)
+    }
 
     /// Non-zero status -> the reference's behaviour for a violated contract: trap.
     @inline(__always)
@@ -46,6 +77,7 @@ enum AMD
         l.nplanes   = .init(layout.recognized.count)
         l.scale_x   = .init(layout.scale.x)
         l.scale_y   = .init(layout.scale.y)
+        // the C arrays are imported as homogeneous tuples: written through their raw bytes, inside the closures
         withUnsafeMutableBytes(of: &l.factor_x){ f in
         withUnsafeMutableBytes(of: &l.factor_y){ g in
         withUnsafeMutableBytes(of: &l.units_x ){ u in
@@ -63,15 +95,46 @@ enum AMD
         return l
     }
 
-    /// Calls `body` with an array of base addresses of `arrays` (all kept alive for the call).
-    static func withPointers<T, R>(_ arrays:[[T]], _ body:([UnsafeRawPointer?]) -> R) -> R
+    /// Calls `body` with the base addresses of `arrays`; every `withUnsafeBufferPointer` scope stays open until
+    /// `body` has returned.
+    static func withPointers<T, R>(_ arrays:[[T]], _ body:([UnsafePointer<T>?]) -> R) -> R
     {
-        func go(_ i:Int, _ acc:[UnsafeRawPointer?]) -> R
+        func go(_ i:Int, _ acc:[UnsafePointer<T>?]) -> R
         {
             guard i < arrays.count else { return body(acc) }
-            return arrays[i].withUnsafeBytes{ go(i + 1, acc + [$0.baseAddress]) }
+            return arrays[i].withUnsafeBufferPointer{ go(i + 1, acc + [$0.baseAddress]) }
         }
         return go(0, [])
+    }
+    /// The same for arrays that the C side fills in.
+    static func withMutablePointers<T, R>(_ arrays:inout [[T]], _ body:([UnsafeMutablePointer<T>?]) -> R) -> R
+    {
+        // each array is moved out of the outer array while its buffer is borrowed (no copy-on-write copy, no
+        // overlapping access to `arrays`), and moved back afterwards
+        func go(_ i:Int, _ acc:[UnsafeMutablePointer<T>?], _ arrays:inout [[T]]) -> R
+        {
+            guard i < arrays.count else { return body(acc) }
+            var taken:[T] = []
+            swap(&taken, &arrays[i])
+            defer { swap(&taken, &arrays[i]) }
+            return taken.withUnsafeMutableBufferPointer{ go(i + 1, acc + [$0.baseAddress], &arrays) }
+        }
+        return go(0, [], &arrays)
+    }
+
+    /// [table][64] in zigzag order (decode.swift:1289-1326), the form the C ABI takes tables in
+    static func tables<Format>(_ spectral:JPEG.Data.Spectral<Format>) -> [UInt16]
+    {
+        var flat:[UInt16] = []
+        flat.reserveCapacity(64 * spectral.quanta.count)
+        for q in spectral.quanta.indices
+        {
+            for z:Int in 0 ..< 64
+            {
+                flat.append(spectral.quanta[q][z: z])
+            }
+        }
+        return flat
     }
 }
 
@@ -82,25 +145,21 @@ extension JPEG.Data.Spectral
     func idct() -> JPEG.Data.Planar<Format>
     {
         let units:[(x:Int, y:Int)] = self.indices.map{ self[$0].units }
-        var l:jpeg_amd_layout = AMD.layout(self.layout, size: self.size, units: units,
+        var l:jpeg_amd_layout   = AMD.layout(self.layout, size: self.size, units: units,
             q: self.indices.map{ self[$0].q })
-        // quantisation tables, [table][64] zigzag (decode.swift:1289-1326)
-        let quanta:[UInt16] = self.quanta.indices.flatMap{ q in (0 ..< 64).map{ self.quanta[q][z: $0] } }
-        var planes:[[UInt16]] = units.map{ .init(repeating: 0, count: 64 * $0.x * $0.y) }
+        let quanta:[UInt16]     = AMD.tables(self)
+        var planes:[[UInt16]]   = units.map{ .init(repeating: 0, count: 64 * $0.x * $0.y) }
         let status:Int32 = AMD.withPointers(self.indices.map{ self[$0].buffer })
         {
-            (coef:[UnsafeRawPointer?]) -> Int32 in
-            var out:[UnsafeMutableRawPointer?] = []
-            for p:Int in planes.indices
+            (coef:[UnsafePointer<Int16>?]) -> Int32 in
+            AMD.withMutablePointers(&planes)
             {
-                planes[p].withUnsafeMutableBytes{ out.append($0.baseAddress) }
+                (out:[UnsafeMutablePointer<UInt16>?]) -> Int32 in
+                AMD.withContext
+                {
+                    jpeg_amd_host_spectral_idct($0, &l, coef, quanta, .init(self.quanta.count), out)
+                }
             }
-            return coef.withUnsafeBufferPointer{ c in out.withUnsafeBufferPointer{ o in
-                jpeg_amd_host_spectral_idct(AMD.context, &l,
-                    UnsafeRawPointer(c.baseAddress!).assumingMemoryBound(to: UnsafePointer<Int16>?.self),
-                    quanta, .init(self.quanta.count),
-                    UnsafeRawPointer(o.baseAddress!).assumingMemoryBound(to: UnsafeMutablePointer<UInt16>?.self))
-            }}
         }
         AMD.check(status, "jpeg_amd_host_spectral_idct")
         return .init(size: self.size, layout: self.layout, metadata: self.metadata,
@@ -118,15 +177,21 @@ extension JPEG.Data.Planar
     {
         var l:jpeg_amd_layout = AMD.layout(self.layout, size: self.size,
             units: self.indices.map{ self[$0].units }, q: self.indices.map{ _ in 0 })
-        var values:[UInt16] = .init(repeating: 0, count: self.size.x * self.size.y * self.count)
-        let status:Int32 = AMD.withPointers(self.indices.map{ self[$0].buffer })
+        let count:Int = self.size.x * self.size.y * self.count
+        var status:Int32 = 0
+        let values:[UInt16] = .init(unsafeUninitializedCapacity: count)
         {
-            (planes:[UnsafeRawPointer?]) -> Int32 in
-            planes.withUnsafeBufferPointer{ p in
-                jpeg_amd_host_planar_interleaved(AMD.context, &l,
-                    UnsafeRawPointer(p.baseAddress!).assumingMemoryBound(to: UnsafePointer<UInt16>?.self),
-                    cosited ? 1 : 0, &values)
+            (buffer:inout UnsafeMutableBufferPointer<UInt16>, initialized:inout Int) in
+            status = AMD.withPointers(self.indices.map{ self[$0].buffer })
+            {
+                (planes:[UnsafePointer<UInt16>?]) -> Int32 in
+                AMD.withContext
+                {
+                    jpeg_amd_host_planar_interleaved($0, &l, planes, cosited ? 1 : 0, buffer.baseAddress)
+                }
             }
+            if status != 0 { buffer.initialize(repeating: 0) }
+            initialized = count
         }
         AMD.check(status, "jpeg_amd_host_planar_interleaved")
         return .init(size: self.size, layout: self.layout, metadata: self.metadata, values: values)
@@ -141,22 +206,20 @@ extension JPEG.Data.Planar
         let units:[(x:Int, y:Int)] = self.indices.map{ self[$0].units }
         var l:jpeg_amd_layout = AMD.layout(self.layout, size: self.size, units: units,
             q: spectral.indices.map{ spectral[$0].q })
-        let tables:[UInt16] = spectral.quanta.indices.flatMap{ q in (0 ..< 64).map{ spectral.quanta[q][z: $0] } }
-        var coef:[[Int16]] = units.map{ .init(repeating: 0, count: 64 * $0.x * $0.y) }
+        let tables:[UInt16]   = AMD.tables(spectral)
+        let ntables:Int32     = .init(spectral.quanta.count)
+        var coef:[[Int16]]    = units.map{ .init(repeating: 0, count: 64 * $0.x * $0.y) }
         let status:Int32 = AMD.withPointers(self.indices.map{ self[$0].buffer })
         {
-            (planes:[UnsafeRawPointer?]) -> Int32 in
-            var out:[UnsafeMutableRawPointer?] = []
-            for p:Int in coef.indices
+            (planes:[UnsafePointer<UInt16>?]) -> Int32 in
+            AMD.withMutablePointers(&coef)
             {
-                coef[p].withUnsafeMutableBytes{ out.append($0.baseAddress) }
+                (out:[UnsafeMutablePointer<Int16>?]) -> Int32 in
+                AMD.withContext
+                {
+                    jpeg_amd_host_planar_fdct($0, &l, planes, tables, ntables, out)
+                }
             }
-            return planes.withUnsafeBufferPointer{ p in out.withUnsafeBufferPointer{ o in
-                jpeg_amd_host_planar_fdct(AMD.context, &l,
-                    UnsafeRawPointer(p.baseAddress!).assumingMemoryBound(to: UnsafePointer<UInt16>?.self),
-                    tables, .init(spectral.quanta.count),
-                    UnsafeRawPointer(o.baseAddress!).assumingMemoryBound(to: UnsafeMutablePointer<Int16>?.self))
-            }}
         }
         AMD.check(status, "jpeg_amd_host_planar_fdct")
         for (p, values):(Int, [Int16]) in zip(spectral.indices, coef)
@@ -172,39 +235,85 @@ extension JPEG.Data.Planar
 
 extension JPEG.Data.Rectangular where Format == JPEG.Common
 {
-    /// unpack(as:) for the two built-in colour targets; other `JPEG.Color` conformances keep
-    /// the reference's generic path (`Color.unpack(self.values, of:)`).
+    // JPEG.RGB and JPEG.YCbCr are three stored UInt8 each, declared in channel order (jpeg.swift:160-269): an array
+    // of them IS the byte layout uint8 [pixel][3] the C ABI writes.  Checked once, not assumed.
+    private static
+    func checkLayout<Color>(_:Color.Type)
+    {
+        precondition(MemoryLayout<Color>.size == 3 && MemoryLayout<Color>.stride == 3 &&
+            MemoryLayout<Color>.alignment == 1, "\(Color.self) is not three packed bytes")
+    }
+    private
+    func unpack<Color>(_:Color.Type, color:jpeg_amd_color) -> [Color]
+    {
+        Self.checkLayout(Color.self)
+        let n:Int = self.size.x * self.size.y
+        var status:Int32 = 0
+        let pixels:[Color] = .init(unsafeUninitializedCapacity: n)
+        {
+            (buffer:inout UnsafeMutableBufferPointer<Color>, initialized:inout Int) in
+            let raw:UnsafeMutableRawBufferPointer = .init(buffer)
+            status = AMD.withContext
+            {
+                jpeg_amd_host_rectangular_unpack($0, self.values, n, .init(self.stride), color,
+                    raw.baseAddress?.assumingMemoryBound(to: UInt8.self))
+            }
+            if status != 0 { raw.initializeMemory(as: UInt8.self, repeating: 0) }
+            initialized = n
+        }
+        AMD.check(status, "jpeg_amd_host_rectangular_unpack")
+        return pixels
+    }
+    /// unpack(as:) for the two built-in colour targets; other `JPEG.Color` conformances take the reference's
+    /// generic definition (`Color.unpack(self.values, of:)`), which is left in place.
     public
     func unpack(as _:JPEG.RGB.Type) -> [JPEG.RGB]
     {
-        self.unpack(color: JPEG_AMD_COLOR_RGB8).map{ .init($0.0, $0.1, $0.2) }
+        self.unpack(JPEG.RGB.self, color: JPEG_AMD_COLOR_RGB8)
     }
     public
     func unpack(as _:JPEG.YCbCr.Type) -> [JPEG.YCbCr]
     {
-        self.unpack(color: JPEG_AMD_COLOR_YCC8).map{ .init(y: $0.0, cb: $0.1, cr: $0.2) }
-    }
-    private
-    func unpack(color:jpeg_amd_color) -> [(UInt8, UInt8, UInt8)]
-    {
-        let n:Int = self.size.x * self.size.y
-        var bytes:[UInt8] = .init(repeating: 0, count: 3 * n)
-        AMD.check(jpeg_amd_host_rectangular_unpack(AMD.context, self.values, n,
-            .init(self.stride), color, &bytes), "jpeg_amd_host_rectangular_unpack")
-        return (0 ..< n).map{ (bytes[3 * $0], bytes[3 * $0 + 1], bytes[3 * $0 + 2]) }
+        self.unpack(JPEG.YCbCr.self, color: JPEG_AMD_COLOR_YCC8)
     }
 
+    private static
+    func pack<Color>(size:(x:Int, y:Int), layout:JPEG.Layout<Format>, metadata:[JPEG.Metadata],
+        pixels:[Color], color:jpeg_amd_color) -> Self
+    {
+        Self.checkLayout(Color.self)
+        let count:Int = layout.recognized.count * pixels.count
+        var status:Int32 = 0
+        let values:[UInt16] = .init(unsafeUninitializedCapacity: count)
+        {
+            (buffer:inout UnsafeMutableBufferPointer<UInt16>, initialized:inout Int) in
+            status = pixels.withUnsafeBytes
+            {
+                (bytes:UnsafeRawBufferPointer) -> Int32 in
+                AMD.withContext
+                {
+                    jpeg_amd_host_rectangular_pack($0, bytes.baseAddress?.assumingMemoryBound(to: UInt8.self),
+                        pixels.count, .init(layout.recognized.count), color, buffer.baseAddress)
+                }
+            }
+            if status != 0 { buffer.initialize(repeating: 0) }
+            initialized = count
+        }
+        AMD.check(status, "jpeg_amd_host_rectangular_pack")
+        // the initializer keeps the reference's preconditions (decode.swift:1710-1712)
+        return .init(size: size, layout: layout, metadata: metadata, values: values)
+    }
     public static
     func pack(size:(x:Int, y:Int), layout:JPEG.Layout<Format>, metadata:[JPEG.Metadata],
         pixels:[JPEG.RGB]) -> Self
     {
-        let bytes:[UInt8] = pixels.flatMap{ [$0.r, $0.g, $0.b] }
-        var values:[UInt16] = .init(repeating: 0, count: layout.recognized.count * pixels.count)
-        AMD.check(jpeg_amd_host_rectangular_pack(AMD.context, bytes, pixels.count,
-            .init(layout.recognized.count), JPEG_AMD_COLOR_RGB8, &values),
-            "jpeg_amd_host_rectangular_pack")
-        // the initializer keeps the reference's preconditions (decode.swift:1710-1712)
-        return .init(size: size, layout: layout, metadata: metadata, values: values)
+        Self.pack(size: size, layout: layout, metadata: metadata, pixels: pixels, color: JPEG_AMD_COLOR_RGB8)
+    }
+    public static
+    func pack(size:(x:Int, y:Int), layout:JPEG.Layout<Format>, metadata:[JPEG.Metadata],
+        pixels:[JPEG.YCbCr]) -> Self
+    {
+        Self.pack(size: size, layout: layout, metadata: metadata, pixels: pixels, color: JPEG_AMD_COLOR_YCC8)
     }
 }
 
@@ -213,38 +322,35 @@ extension JPEG.Data.Rectangular
     public
     func decomposed() -> JPEG.Data.Planar<Format>
     {
-        // Planar.init computes units = ceil(size * factor / (8 * scale)) per plane
-        // (decode.swift:2606-2616) and hands us each plane's uninitialised buffer; the first
-        // call runs the GPU kernels for every plane, later calls copy out of the cache.
-        var cache:[[UInt16]] = []
+        // The device computes every plane in one call, into arrays sized by the same formula Planar.init uses
+        // (units = ceil(size * factor / (8 * scale)), decode.swift:2606-2616; jpeg_amd_layout_units); Planar's
+        // generator initializer then hands over each plane's uninitialised buffer and gets a copy.
+        var l:jpeg_amd_layout = AMD.layout(self.layout, size: self.size,
+            units: self.layout.recognized.indices.map{ _ in (0, 0) },
+            q: self.layout.recognized.indices.map{ _ in 0 })
+        AMD.check(jpeg_amd_layout_units(&l), "jpeg_amd_layout_units")
+        var planes:[[UInt16]] = withUnsafeBytes(of: l.units_x){ ux in withUnsafeBytes(of: l.units_y){ uy in
+            self.layout.recognized.indices.map
+            {
+                .init(repeating: 0, count: 64 *
+                    Int(ux.load(fromByteOffset: 4 * $0, as: Int32.self)) *
+                    Int(uy.load(fromByteOffset: 4 * $0, as: Int32.self)))
+            }
+        }}
+        let status:Int32 = AMD.withMutablePointers(&planes)
+        {
+            (out:[UnsafeMutablePointer<UInt16>?]) -> Int32 in
+            AMD.withContext
+            {
+                jpeg_amd_host_rectangular_decomposed($0, &l, self.values, out)
+            }
+        }
+        AMD.check(status, "jpeg_amd_host_rectangular_decomposed")
         return .init(size: self.size, layout: self.layout, metadata: self.metadata)
         {
             (p:Int, units:(x:Int, y:Int), factor:(x:Int, y:Int), buffer:UnsafeMutableBufferPointer<UInt16>) in
-            if cache.isEmpty
-            {
-                var l:jpeg_amd_layout = AMD.layout(self.layout, size: self.size,
-                    units: self.layout.recognized.indices.map{ _ in (0, 0) },
-                    q: self.layout.recognized.indices.map{ _ in 0 })
-                AMD.check(jpeg_amd_layout_units(&l), "jpeg_amd_layout_units")
-                cache = withUnsafeBytes(of: l.units_x){ ux in withUnsafeBytes(of: l.units_y){ uy in
-                    self.layout.recognized.indices.map
-                    {
-                        .init(repeating: 0, count: 64 *
-                            Int(ux.load(fromByteOffset: 4 * $0, as: Int32.self)) *
-                            Int(uy.load(fromByteOffset: 4 * $0, as: Int32.self)))
-                    }
-                }}
-                var out:[UnsafeMutableRawPointer?] = []
-                for q:Int in cache.indices
-                {
-                    cache[q].withUnsafeMutableBytes{ out.append($0.baseAddress) }
-                }
-                AMD.check(out.withUnsafeBufferPointer{ o in
-                    jpeg_amd_host_rectangular_decomposed(AMD.context, &l, self.values,
-                        UnsafeRawPointer(o.baseAddress!).assumingMemoryBound(to: UnsafeMutablePointer<UInt16>?.self))
-                }, "jpeg_amd_host_rectangular_decomposed")
-            }
-            _ = buffer.initialize(from: cache[p])
+            precondition(buffer.count == planes[p].count, "plane \(p): \(buffer.count) samples, expected \(planes[p].count)")
+            _ = buffer.initialize(from: planes[p])
         }
     }
 }

@@ -26,13 +26,15 @@
 #include "dct.hpp"
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace jpeg_amd {
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int ETX = 32;  // luma blocks per tile row
-constexpr int ETY = 16;  // luma blocks per tile column
+constexpr int ETY = 16;  // luma blocks per tile column (8 for the small-image variant, template parameter TY)
 
 struct EncArgs {
     const uint8_t *px;
@@ -146,26 +148,66 @@ __device__ __forceinline__ void wave_store_blocks(const uint32_t (&w)[32], uint3
     }
 }
 
+// The same through a 4 KiB buffer, one half of the wave at a time (lanes 0..31 stage and the whole wave stores their
+// 32 blocks, then lanes 32..63): half the LDS for eight more ds_write instructions.  For the 8-row-tile kernels,
+// which want four workgroups on a CU.
+__device__ __forceinline__ void wave_store_blocks_halves(const uint32_t (&w)[32], uint32_t *stage, int lane,
+                                                         int16_t *plane, uint32_t block)
+{
+    const uint4 *all = reinterpret_cast<const uint4 *>(stage);
+    char *base = reinterpret_cast<char *>(plane);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+            uint4 *mine = reinterpret_cast<uint4 *>(stage) + 8 * (lane & 31);
+            const int sw = (lane >> 1) & 7;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) mine[c ^ sw] = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int producer = 32 * h + 8 * i + (lane >> 3);
+            const uint32_t blk = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * producer, (int)block);
+            const int c = (lane & 7) ^ ((producer >> 1) & 7);
+            const uint4 v = all[64 * i + lane];
+#ifdef JA_X_ENC_NOSTORE
+            if (plane == nullptr)
+#endif
+            if (blk != ~0u) store_nt16(base + ((size_t)blk << 7) + 16 * c, v);
+        }
+    }
+}
+
 // SX, SY: chroma subsampling (1 or 2) per axis; RGB: input is RGB8 (else YCbCr8);
 // CHROMA = false: single-plane image (only Y is produced);
 // FASTIN: W % 8 == 0 and 8-byte aligned rows (vector loads for blocks inside the image).
-template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN>
-__global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
+// TY: luma block rows per tile.  16: a work-item transforms two luma blocks and (4:2:0) one chroma block.  8: one luma
+// block, and half of the work-items a chroma block -- twice as many workgroups, for images whose 16-row tiles
+// would not fill the chip (a 4096 x 4096 frame is 512 tiles of 16 rows: two waves per SIMD, each of them bound by
+// its own instruction latency).
+template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN, int TY = ETY>
+__global__ __launch_bounds__(kThreads, TY == 8 ? 4 : 3) void k_encode_fused(EncArgs a)
 {
+    constexpr bool HALFSTAGE = TY == 8;                  // 4 KiB of store staging per wave instead of 8
+    static_assert(TY == 16 || (TY == 8 && SX * SY != 2), "the per-half chroma tiles of 4:2:2 / 4:4:0 need 16 block rows");
     constexpr bool INTHREAD = SX == 1 && SY == 1;        // 4:4:4: chroma block == the luma block's pixels
     // 4:2:2 / 4:4:0: the 8 luma block rows of one `half` already hold 256 chroma blocks (one per
     // work-item), so the chroma tile covers one half at a time and stays at 16 KiB
     constexpr bool PERHALF = CHROMA && SX * SY == 2;
-    constexpr int CW = ETX * 8 / SX, CH = (PERHALF ? ETY / 2 : ETY) * 8 / SY;  // chroma samples per tile (or half)
+    constexpr int CW = ETX * 8 / SX, CH = (PERHALF ? TY / 2 : TY) * 8 / SY;  // chroma samples per tile (or half)
     constexpr int CPITCH = CW / 4;                       // dwords per LDS row
     __shared__ uint32_t sc[(CHROMA && !INTHREAD) ? 2 * CH * CPITCH : 1];
-    __shared__ __attribute__((aligned(16))) uint32_t stage_all[kThreads / 64][64 * 32];  // 8 KiB per wave
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[kThreads / 64][HALFSTAGE ? 32 * 32 : 64 * 32];  // 8 (4) KiB per wave
     // 4:4:4: the block's Cb / Cr samples wait here (packed 4 per dword, [dword][lane]) while the
     // luma block is transformed -- in registers they cost 32 VGPRs and the kernel spilled
     __shared__ uint32_t stash_all[(CHROMA && INTHREAD) ? kThreads / 64 : 1][(CHROMA && INTHREAD) ? 32 * 64 : 1];
     __shared__ float sq[3][64];   // modulated tables (scale 8) ...
     __shared__ float sr[3][64];   // ... and their correctly rounded reciprocals
 
+    auto store_blocks = [](const uint32_t (&w)[32], uint32_t *stage, int lane, int16_t *plane, uint32_t block) {
+        if constexpr (HALFSTAGE) wave_store_blocks_halves(w, stage, lane, plane, block);
+        else wave_store_blocks(w, stage, lane, plane, block);
+    };
     const int img = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
     const int lbx = threadIdx.x & (ETX - 1), lby0 = threadIdx.x / ETX;
@@ -183,12 +225,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
 
     // chroma blocks of the tile (or of one half of it) from the pooled LDS tile
     auto chroma_blocks = [&](int half) {
-        constexpr int CBX = ETX / SX, CBY = (PERHALF ? ETY / 2 : ETY) / SY;  // chroma blocks per plane
+        constexpr int CBX = ETX / SX, CBY = (PERHALF ? TY / 2 : TY) / SY;  // chroma blocks per plane
 #pragma unroll 1
         for (int c = threadIdx.x; c < 2 * CBX * CBY; c += kThreads) {
             const int pl = c / (CBX * CBY), r = c - pl * (CBX * CBY);
             const int cby = r / CBX, cbx = r - cby * CBX;
-            const int bx = txi * CBX + cbx, by = tyi * (ETY / SY) + half * CBY + cby;
+            const int bx = txi * CBX + cbx, by = tyi * (TY / SY) + half * CBY + cby;
             float g[64];
 #pragma unroll
             for (int y = 0; y < 8; ++y) {
@@ -205,15 +247,15 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
             // never straddles the two planes
             const int plu = __builtin_amdgcn_readfirstlane(pl);
             const uint32_t off = (bx < a.ux[1 + plu] && by < a.uy[1 + plu]) ? (uint32_t)(by * a.ux[1 + plu] + bx) : ~0u;
-            wave_store_blocks(w, stage, lane, a.coef[1 + plu] + img * a.coef_stride[1 + plu], off);
+            store_blocks(w, stage, lane, a.coef[1 + plu] + img * a.coef_stride[1 + plu], off);
         }
     };
 
     const uint8_t *base = a.px + img * a.px_stride;
 #pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < TY / 8; ++half) {
         const int lby = lby0 + 8 * half;
-        const int bx = txi * ETX + lbx, by = tyi * ETY + lby;
+        const int bx = txi * ETX + lbx, by = tyi * TY + lby;
         float yv[64];
 
         // one pixel row of the block: Y stays in registers for the FDCT; Cb / Cr are pooled by
@@ -324,7 +366,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
             uint32_t w[32];
             fdct_quantise(yv, sq[0], sr[0], w);
             const uint32_t off = (bx < a.ux[0] && by < a.uy[0]) ? (uint32_t)(by * a.ux[0] + bx) : ~0u;
-            wave_store_blocks(w, stage, lane, a.coef[0] + img * a.coef_stride[0], off);
+            store_blocks(w, stage, lane, a.coef[0] + img * a.coef_stride[0], off);
         }
         if constexpr (CHROMA && INTHREAD) {
 #pragma unroll 1
@@ -339,7 +381,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
                 uint32_t w[32];
                 fdct_quantise(g, sq[1 + pl], sr[1 + pl], w);
                 const uint32_t off = (bx < a.ux[1 + pl] && by < a.uy[1 + pl]) ? (uint32_t)(by * a.ux[1 + pl] + bx) : ~0u;
-                wave_store_blocks(w, stage, lane, a.coef[1 + pl] + img * a.coef_stride[1 + pl], off);
+                store_blocks(w, stage, lane, a.coef[1 + pl] + img * a.coef_stride[1 + pl], off);
             }
         }
         if constexpr (PERHALF) {
@@ -356,6 +398,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_encode_fused(EncArgs a)
 }
 
 }  // namespace
+
+// development switch: JPEG_AMD_ENC_TY=8 / 16 forces the tile height of the grey / 4:2:0 encode kernels
+static int encode_ty_override()
+{
+    static const int v = [] { const char *e = std::getenv("JPEG_AMD_ENC_TY"); return e ? std::atoi(e) : 0; }();
+    return v;
+}
 
 bool fused_encode_supported(const jpeg_amd_layout &L)
 {
@@ -395,14 +444,23 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     const int need_x = chroma ? max(a.ux[0], sx * a.ux[1]) : a.ux[0];
     const int need_y = chroma ? max(a.uy[0], sy * a.uy[1]) : a.uy[0];
     a.tiles_x = (need_x + ETX - 1) / ETX;
-    const int tiles_y = (need_y + ETY - 1) / ETY;
+    // grey and 4:2:0 take the 8-row tiles (one luma block per work-item, four waves per SIMD): measured faster than the
+    // 16-row tiles at every size (tools/bench_encode.py, JPEG_AMD_ENC_TY=16 / 8: 4096 x 4096 4:2:0 30.9 -> 28.8 us, 8192 x 8192
+    // 103.6 -> 97.5, 2048 x 2048 23.3 -> 15.4, grey 4096 x 4096 21.2 -> 16.9).  4:2:2 / 4:4:0 pool chroma per half tile and
+    // 4:4:4 parks it per lane: those keep 16 rows.
+    const bool can8 = !chroma || (sx == 2 && sy == 2);
+    const int ty = can8 && encode_ty_override() != 16 ? 8 : 16;
+    const int tiles_y = (need_y + ty - 1) / ty;
     if (a.tiles_x * tiles_y == 0 || n_images == 0) return hipSuccess;
     const dim3 grid(a.tiles_x * tiles_y, n_images);
     const bool fast = (L.width & 7) == 0 && (pixel_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 7) == 0;
 #define JA_E(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_>), grid, dim3(kThreads), 0, stream, a)
+#define JA_E8(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_, 8>), grid, dim3(kThreads), 0, stream, a)
 #define JA_E2(RGB_, F_)                                         \
     do {                                                        \
-        if (!chroma) JA_E(1, 1, RGB_, false, F_);               \
+        if (!chroma && ty == 8) JA_E8(1, 1, RGB_, false, F_);   \
+        else if (!chroma) JA_E(1, 1, RGB_, false, F_);          \
+        else if (sx == 2 && sy == 2 && ty == 8) JA_E8(2, 2, RGB_, true, F_); \
         else if (sx == 2 && sy == 2) JA_E(2, 2, RGB_, true, F_); \
         else if (sx == 2 && sy == 1) JA_E(2, 1, RGB_, true, F_); \
         else if (sx == 1 && sy == 2) JA_E(1, 2, RGB_, true, F_); \
@@ -411,6 +469,7 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     if (rgb) { if (fast) JA_E2(true, true); else JA_E2(true, false); }
     else     { if (fast) JA_E2(false, true); else JA_E2(false, false); }
 #undef JA_E2
+#undef JA_E8
 #undef JA_E
     return hipGetLastError();
 }

@@ -98,6 +98,85 @@ __global__ __launch_bounds__(kThreads) void k_chroma_idct(ChromaArgs a)
     }
 }
 
+// The same, persistent and software-pipelined: a wave walks units of 64 consecutive blocks (u, u + nwaves, ...) and the
+// 128 bytes of its NEXT block are requested before the current one is transformed.  k_chroma_idct starts all its
+// workgroups at once -- the whole chip loads, then the whole chip computes, then it stores (a round is memory time PLUS
+// arithmetic time: 24 us for 100 MB and 7 M VALU instructions at 8192 x 8192); here every wave always has a block in
+// flight while it works on another.  Units are per (image, plane): `units_per_plane` x 64 blocks cover the launch's
+// block range, so a wave never straddles two tables.
+struct ChromaPersistArgs {
+    ChromaArgs c;
+    int n_images, units_per_plane, total_units;
+};
+
+__global__ __launch_bounds__(kThreads, 3) void k_chroma_idct_persist(ChromaPersistArgs p)
+{
+    const ChromaArgs &a = p.c;
+    __shared__ float sqw[kThreads / 64][64];
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *sq = sqw[wave];
+    const int nwaves = gridDim.x * (kThreads / 64);
+    int u = blockIdx.x * (kThreads / 64) + wave;
+    if (u >= p.total_units) return;
+
+    auto source = [&](int unit, int ln, int &img, int &pl, int &b) -> const uint4 * {
+        const int ip = unit / p.units_per_plane;
+        img = ip >> 1; pl = ip & 1;
+        b = a.first_block + 64 * (unit - ip * p.units_per_plane) + ln;
+        const int bc = min(b, a.end_block - 1);       // lanes past the range re-read the last block; nothing is stored
+        return reinterpret_cast<const uint4 *>(a.coef[pl] + img * a.coef_stride[pl] + (size_t)64 * bc);
+    };
+    uint32_t wn[32];
+    auto fetch = [&](const uint4 *src) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 v = src[i];
+            wn[4 * i + 0] = v.x; wn[4 * i + 1] = v.y; wn[4 * i + 2] = v.z; wn[4 * i + 3] = v.w;
+        }
+    };
+    int img, pl, b;
+    fetch(source(u, lane0, img, pl, b));
+    int table_of = -1;
+    for (; u < p.total_units; u += nwaves) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        (void)source(u, lane, img, pl, b);
+        const int ip = 2 * img + pl;
+        if (ip != table_of) {   // wave-uniform
+            const int k = lane & 7, h = lane >> 3;
+            sq[lane] = modulate_entry(k, h, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi[pl] + zigzag_of(k, h)]);
+            table_of = ip;
+        }
+        uint32_t w[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) w[i] = wn[i];
+        if (u + nwaves < p.total_units) {
+            int i2, p2, b2;
+            fetch(source(u + nwaves, lane, i2, p2, b2));
+        }
+        float g[64];
+        idct_block(w, sq, 128.5f, g);  // level = 2^(P-1) + 0.5, P = 8
+        asm volatile("" : "+v"(lane));
+        if (b < a.end_block) {
+            const int by = b / a.ux, bx = b - by * a.ux;
+            const size_t pitch = (size_t)8 * a.ux;
+            uint8_t *dst = a.out[pl] + img * a.out_stride + (size_t)8 * by * pitch + 8 * bx;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                // clamp [0, 255] + truncate == saturating convert of floor(v)
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    lo = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + x]), x, lo);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 + x]), x, hi);
+                }
+                *reinterpret_cast<uint2 *>(dst + y * pitch) = make_uint2(lo, hi);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // K2: luma IDCT + chroma upsample + colour + store
 // ---------------------------------------------------------------------------------------
@@ -1072,6 +1151,28 @@ hipError_t launch_luma_any(hipStream_t stream, const LumaArgs &la, int bx, int s
 #undef JA_L
 }
 
+// resident waves of k_chroma_idct_persist (4 workgroups per CU by its launch bounds), and a development switch
+inline int chroma_persist_waves()
+{
+    static const int v = [] {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chroma_idct_persist, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        return per_cu * cus * (kThreads / 64);
+    }();
+    return v;
+}
+inline bool chroma_persist_enabled()
+{
+    // OFF by default: measured slower (tools/ab_band.py --env=JPEG_AMD_K1_PERSIST): 103.8 vs 100.4 us per 8192 x 8192 step at
+    // three waves per SIMD (168 VGPRs), 125 vs 100 us at four (128 VGPRs, 41 of them spilled) -- like the LDS-DMA
+    // variant of round 1 (26-35 vs 25 us).  The one-shot kernel's memory and arithmetic phases do not overlap, but its
+    // five waves per SIMD at 94 VGPRs make up for it.
+    static const bool v = [] { const char *e = std::getenv("JPEG_AMD_K1_PERSIST"); return e && e[0] == '1'; }();
+    return v;
+}
+
 // JPEG_AMD_OVERLAP=1 pipelines the two launches of a 4:2:0 / 4:4:0 decode over parts of the call on the context's
 // helper streams (OverlapLanes).  OFF by default -- measured on MI355X (tools/ab_band.py --env=JPEG_AMD_OVERLAP):
 // the cross-stream event waits cost more than the overlap returns.  One 8192 x 8192 image as two halves 139 us
@@ -1148,6 +1249,12 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
         for (int i = 0; i < 2; ++i) { c.coef[i] += (size_t)i0 * c.coef_stride[i]; c.out[i] += (size_t)i0 * c.out_stride; }
         c.quanta += (size_t)i0 * c.quanta_stride;
         c.first_block = b0; c.end_block = b1;
+        const long units_per_plane = ((long)(b1 - b0) + 63) / 64, total_units = units_per_plane * 2 * (i1 - i0);
+        if (chroma_persist_enabled() && total_units >= 2 * chroma_persist_waves() && total_units < 0x7fffffffL) {
+            ChromaPersistArgs pa{c, i1 - i0, (int)units_per_plane, (int)total_units};
+            hipLaunchKernelGGL(k_chroma_idct_persist, dim3(chroma_persist_waves() / (kThreads / 64)), dim3(kThreads), 0, st, pa);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(k_chroma_idct, dim3(blocks_for(b1 - b0), i1 - i0, 2), dim3(kThreads), 0, st, c);
         return hipGetLastError();
     };

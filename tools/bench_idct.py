@@ -6,10 +6,11 @@ import numpy as np, torch
 import jpeg_amd as J
 from jpeg_amd import _lib, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--units", type=int, default=2048); ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--only-main", action="store_true", help="the 2^22-block plane only (profiler runs)")
 args = ap.parse_args()
 ctx = J.Context(0); dev = ctx.torch_device; lib = _lib.lib()
 q = np.ascontiguousarray(J.compression_quanta("luminance", 1.0))
-for ux, uy in [(args.units, args.units), (512, 512), (313, 320)]:
+for ux, uy in ([(args.units, args.units)] if args.only_main else [(args.units, args.units), (512, 512), (313, 320)]):
     ring = 3
     coef = synth.natural_planes_torch([(ux, uy)], ring, dev, 99)[0]
     plane = torch.empty((ring, 64 * ux * uy), dtype=torch.int16, device=dev)

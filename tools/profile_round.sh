@@ -25,7 +25,7 @@ run_cfg() {
 }
 run_cfg c3 $R/bench.py --workload c3 --steps 50 --warmup 10 --no-extras --no-cpu
 run_cfg c5 $R/bench.py --workload c5 --steps 5 --warmup 2 --no-extras --no-cpu
-run_cfg c2 $R/tools/bench_idct.py --units 2048
+run_cfg c2 $R/tools/bench_idct.py --units 2048 --only-main
 run_cfg c4 $R/tools/bench_encode.py --only 4:2:0
 cd $R
 python3 tools/make_traffic.py $O $tag > $O/traffic.json

@@ -301,14 +301,17 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
         if os.path.exists(tpath) and device_kind == "cuda":
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") != workload:
-                    traffic_note = f"profiles/traffic_latest.json is for workload {tj.get('workload')}"
+                per_step = tj.get("hbm_bytes_per_step") if workload == "c3" else None
+                if workload == "c5" and "c5" in tj:     # measured on the whole 4096-image job: this rank's share of it
+                    per_step = int(round(tj["c5"]["hbm_bytes_per_step"] * wl.n_images / tj["c5"]["images"]))
+                if per_step is None:
+                    traffic_note = f"profiles/traffic_latest.json has no record for workload {workload}"
                 elif tj.get("kernel_source_sha16") != kernel_source_sha16():
                     traffic_note = ("stale: profiles/traffic_latest.json was measured at commit "
                                     f"{tj.get('commit')} with other kernel sources")
                 else:
-                    traffic = tj.get("hbm_bytes_per_step")
-                    traffic_note = f"rocprofv3 PMC passes of this command at commit {tj.get('commit')} (tools/profile_round.sh)"
+                    traffic = per_step
+                    traffic_note = f"rocprofv3 PMC passes of this workload at commit {tj.get('commit')} (tools/profile_round.sh)"
             except Exception as e:
                 traffic_note = repr(e)
         result = {

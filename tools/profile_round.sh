@@ -34,6 +34,7 @@ python3 - <<PY
 import json
 t = json.load(open("$O/traffic.json"))
 c3 = dict(t["configs"]["c3"]); c3.update({k: t[k] for k in ("commit", "kernel_source_sha16", "bench_sha16", "method")}); c3["workload"] = "c3"
+c3["c5"] = dict(t["configs"]["c5"], images=4096)     # bench.py --workload c5 scales it by the rank's share of the images
 json.dump(c3, open("profiles/traffic_latest.json", "w"), indent=1)
 PY
 for c in c3 c5 c2 c4; do cp $O/$c/kernel_stats.csv profiles/${tag}_${c}_kernel_stats.csv; cp $O/$c/pmc_fetch_size.csv profiles/${tag}_${c}_pmc_fetch_size.csv; cp $O/$c/pmc_write_size.csv profiles/${tag}_${c}_pmc_write_size.csv; done

@@ -186,8 +186,10 @@ __device__ __forceinline__ void wave_store_blocks_halves(const uint32_t (&w)[32]
 // would not fill the chip (a 4096 x 4096 frame is 512 tiles of 16 rows: two waves per SIMD, each of them bound by
 // its own instruction latency).
 template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN, int TY = ETY>
-__global__ __launch_bounds__(kThreads, TY == 8 ? 4 : 3) void k_encode_fused(EncArgs a)
+__global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY == 1) ? 2 : 3)) void k_encode_fused(EncArgs a)
 {
+    // (waves per SIMD declared above: 4 for the 8-row tiles, 2 for 4:4:4 -- its 65 KiB of LDS and 256 VGPRs admit no
+    // more -- and 3 otherwise)
     constexpr bool HALFSTAGE = TY == 8;                  // 4 KiB of store staging per wave instead of 8
     static_assert(TY == 16 || (TY == 8 && SX * SY != 2), "the per-half chroma tiles of 4:2:2 / 4:4:0 need 16 block rows");
     constexpr bool INTHREAD = SX == 1 && SY == 1;        // 4:4:4: chroma block == the luma block's pixels

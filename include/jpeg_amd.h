@@ -225,7 +225,9 @@ int jpeg_amd_huffman_build(const int64_t freq[256], uint8_t counts[16], uint8_t 
 /* parse the headers (and walk the scans) without decoding: geometry for buffer allocation */
 int jpeg_amd_jpeg_inspect(const uint8_t *h_jpeg, size_t nbytes, jpeg_amd_frame_info *info);
 /* entropy-decode every scan into caller-allocated planes h_coef[c]: int16 [units_y][units_x][64]
- * zigzag (zeroed here first); h_quanta[c] receives the table bound to component c (zigzag). */
+ * zigzag (zeroed here first); h_quanta[c] receives the table bound to component c (zigzag).
+ * Damaged entropy-coded data is decoded the way the reference decodes it, not refused: a 16-bit window that matches
+ * no codeword is symbol 0 of length 16 (decode.swift:1255-1258), a stream that ends early is padded with 1-bits. */
 int jpeg_amd_jpeg_decode_spectral(const uint8_t *h_jpeg, size_t nbytes, int16_t *const h_coef[],
                                   uint16_t h_quanta[][64], jpeg_amd_frame_info *info);
 /* The same with the restart intervals of every scan decoded by `nthreads` host threads
@@ -245,7 +247,10 @@ int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *h_jpeg, size_t nbytes, 
  * segment and every scan that is complete by then is consumed, incomplete ones wait for the next
  * push.  *scans_done counts the scans decoded so far, *finished is set at EOI.  The decoder owns
  * the planes; jpeg_amd_stream_snapshot copies them (and the table of every component, ones for a
- * component no scan has reached yet) into caller buffers sized from jpeg_amd_stream_info. */
+ * component no scan has reached yet) into caller buffers sized from jpeg_amd_stream_info.
+ * Because it owns the planes it refuses frames of more than 32 Mi blocks in all (ENOMEM; larger frames go through
+ * the one-shot entry points, where the caller allocates), and its first error is final: every later push returns
+ * the same status without touching the decoder's state. */
 typedef struct jpeg_amd_stream jpeg_amd_stream;
 jpeg_amd_stream *jpeg_amd_stream_create(void);
 void jpeg_amd_stream_destroy(jpeg_amd_stream *stream);

@@ -264,6 +264,7 @@ __device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32
 #ifdef JA_PHASE_PROFILE
 // development aid (tools/phase_profile.py): wall cycles each wave spends per phase of a strip
 __device__ unsigned long long g_phase_cycles[4096 * 8];
+__device__ unsigned long long g_wave_info[4096 * 4];   // start tick, end tick (100 MHz counter), HW_ID, XCC_ID
 #define JA_PHASE(i)                                                       \
     {                                                                     \
         const unsigned long long t_now = __builtin_readcyclecounter();    \
@@ -276,12 +277,19 @@ __device__ unsigned long long g_phase_cycles[4096 * 8];
 
 // Waves per SIMD a variant is built for: what its LDS footprint admits (three workgroups of ~51 KiB per CU for 4:2:0 and
 // grey; the layouts with a full-width or full-height chroma tile and 4:4:4 need 58-75 KiB per workgroup: two).
-template <int SX, int SY, bool CHROMA, bool DIRECT>
-constexpr int luma_waves_per_simd() { return (CHROMA && (SX == 1 || SY == 1)) ? 2 : 3; }
+template <int SX, int SY, bool CHROMA, bool DIRECT, bool ALIAS = false>
+constexpr int luma_waves_per_simd() { return ALIAS ? 4 : (CHROMA && (SX == 1 || SY == 1)) ? 2 : 3; }
 
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false>
-__global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRECT>())) void k_luma_fused(LumaArgs a)
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false, bool ALIAS = false>
+__global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRECT, ALIAS>())) void k_luma_fused(LumaArgs a)
 {
+    // ALIAS (two-launch 4:2:0): the chroma tile lives INSIDE the wave's coefficient buffer.  The buffer is only needed
+    // from the prefetch of the next strip's coefficients to their read-back at the top of that strip, the tile from
+    // there to the last chroma read of the pixel rows (row 5) -- so the prefetch is issued after row 5 instead of
+    // after the transform and the two never overlap.  The wave's LDS drops from 12.9 to 9.75 KiB: FOUR waves fit a
+    // SIMD (the kernel needs 125 VGPRs), and 4 096 resident waves take the 16 384 strips of an 8192 x 8192 image in
+    // exactly four rounds instead of 5.33 (the thin sixth round of section 6.1 is gone).
+    static_assert(!ALIAS || (CHROMA && SX == 2 && SY == 2 && !STRIP420 && !DIRECT), "ALIAS is built for the two-launch 4:2:0 path");
     // DIRECT: no LDS coefficient buffer and no LDS-DMA -- a work-item loads its own block (8 x 16 B of its 128-byte
     // line) straight into registers, one strip AHEAD: the loads for the next strip are issued in the middle of the
     // pixel rows, when half of the luma samples are consumed and their registers are free.  Saves the 8 DMA
@@ -327,7 +335,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     constexpr int NTAB = INSTRIP ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][DIRECT ? 4 : 64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
-    __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
+    static_assert(!ALIAS || 2 * PLANE <= 64 * 32, "the chroma tile must fit the coefficient buffer");
+    __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : ALIAS ? 1 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
     __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
 
     const int lane0 = threadIdx.x & 63;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     // LDS byte address of the wave's coefficient buffer (low 32 bits of the flat shared address)
     const uint32_t coef_lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)coef_w);
-    uint32_t *sc = scw[wave];
+    uint32_t *sc = ALIAS ? coef_w : scw[wave];
     const uint32_t sc_lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sc);
     float *sq = sqw[wave][0];
@@ -525,9 +534,24 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         //      16 stores behind it. ----
         if constexpr (!DIRECT) {
             if (stores_behind_dma == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (stores_behind_dma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         JA_PHASE(0)
+#ifndef JA_X_NOPRIO
+        // The waves of a SIMD do not advance at the same pace: the scheduler issues the oldest ready wave first, so with
+        // equal shares the first wave of a SIMD is done long before the last (8192 x 8192, four strips each: ends between
+        // 30 and 72 us, tools/phase_profile.py) and the SIMD spends the end of the launch with one or two waves -- too
+        // few to keep it busy.  A wave with more strips left therefore runs at a higher priority: the laggards catch up
+        // and all waves of a SIMD leave within a strip of each other (ends between 47 and 66 us).
+        {
+            const int rem = (a.total_tiles - 1 - s) / nwaves;   // strips after this one
+            if (rem >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (rem == 2) __builtin_amdgcn_s_setprio(2);
+            else if (rem == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         uint32_t w[32];
         auto read_block = [&]() {
             const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
@@ -543,6 +567,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             for (int i = 0; i < 32; ++i) w[i] = wn[i % (DIRECT ? 32 : 1)];
         } else {
             read_block();
+            // ALIAS: the chroma rows are about to land where the coefficients still are
+            if constexpr (ALIAS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         if constexpr (INTHREAD) {
             // Cb, then Cr: while one plane is transformed the next one's coefficients are on their
@@ -804,7 +830,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         }
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
-        if constexpr (!DIRECT) {
+        if constexpr (!DIRECT && !ALIAS) {
             if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, INSTRIP ? 1 : 0);
         }
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
@@ -874,7 +900,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = sg1 * 8u * pitch + 16u * j1;
         const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
-        stores_behind_dma = (FAST && full) ? 16 : 0;
+        stores_behind_dma = (FAST && full) ? (ALIAS ? 6 : 16) : 0;
         JA_PHASE(4)
 
         // One pixel row of the strip's BY block rows at a time.  The row's LDS and memory traffic is software-
@@ -990,6 +1016,12 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 #pragma unroll
                         for (int pl = 0; pl < 2; ++pl) hraw(pl, (y >> 1) + 3, rawn[pl]);
                     }
+                    if constexpr (ALIAS) {
+                        if (y == 5) {   // the tile has been read for the last time: the next strip's coefficients may land on it
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, 0);
+                        }
+                    }
                 } else if (y < 7) {
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) hraw(pl, y + 1, rawn[pl]);
@@ -1005,7 +1037,15 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     phase_acc[6] = __builtin_readcyclecounter() - t_first;
     phase_acc[7] = __builtin_amdgcn_s_memrealtime() - r_first;
     if (lane0 == 0 && blockIdx.x * NW + wave < 4096)
+    {
         for (int i = 0; i < 8; ++i) g_phase_cycles[(blockIdx.x * NW + wave) * 8 + i] = phase_acc[i];
+        unsigned long long *wi = g_wave_info + (blockIdx.x * NW + wave) * 4;
+        wi[0] = r_first; wi[1] = r_first + phase_acc[7];
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        wi[2] = hw; wi[3] = xcc & 15u;
+    }
 #endif
 }
 
@@ -1013,12 +1053,12 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kT
 
 // Persistent grid = what is resident at once: workgroups per CU (LDS- and VGPR-bound, differs per
 // instantiation: 3 for 4:2:0 and grey, 2 for the variants with a full-width chroma tile) x CUs.
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false>
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false, bool ALIAS = false>
 int resident_workgroups()
 {
     static int cached = 0;  // one per instantiation
     if (cached == 0) {
-        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX, STRIP420, DIRECT>;
+        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX, STRIP420, DIRECT, ALIAS>;
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1032,6 +1072,16 @@ int resident_workgroups()
 inline bool direct_420()
 {
     static const bool v = [] { const char *e = std::getenv("JPEG_AMD_DIRECT"); return e && e[0] == '1'; }();
+    return v;
+}
+
+// development switch: JPEG_AMD_ALIAS=1 selects the four-waves-per-SIMD 4:2:0 luma kernel whose chroma tile lives inside the
+// coefficient buffer.  OFF by default: bit-identical and no faster in sustained runs (tools/ab_band.py --env=JPEG_AMD_ALIAS:
+// 102.2 vs 103.1 us at 8192 x 8192, 1 470 vs 1 478 us for 512 x 1080p) -- its waves advance 4/3 slower and the shader
+// clock drops from 2.03 to 1.81 GHz (tools/phase_profile.py): the step runs at the package power limit either way.
+inline bool alias_420()
+{
+    static const bool v = [] { const char *e = std::getenv("JPEG_AMD_ALIAS"); return e && e[0] == '1'; }();
     return v;
 }
 
@@ -1055,6 +1105,11 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
     else if (sx == 2 && sy == 2 && direct_420()) {
         auto k = k_luma_fused<2, 2, MODE, true, FAST, BX, false, true>;
         const int cap = resident_workgroups<2, 2, MODE, true, FAST, BX, false, true>();
+        hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a);
+    }
+    else if (sx == 2 && sy == 2 && alias_420()) {
+        auto k = k_luma_fused<2, 2, MODE, true, FAST, BX, false, false, true>;
+        const int cap = resident_workgroups<2, 2, MODE, true, FAST, BX, false, false, true>();
         hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a);
     }
     else if (sx == 2 && sy == 2) JA_K(2, 2, true)
@@ -1101,6 +1156,10 @@ inline int strip_width(int ux, int uy, int sx, int sy)
 extern "C" int jpeg_amd_debug_phase_cycles(unsigned long long *h_out, size_t n)
 {
     return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_phase_cycles), n * sizeof(unsigned long long));
+}
+extern "C" int jpeg_amd_debug_wave_info(unsigned long long *h_out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_wave_info), n * sizeof(unsigned long long));
 }
 #endif
 

@@ -1,7 +1,7 @@
 """The opt-in variants of the fused 4:2:0 decode stay bit-identical to the oracle: the band-walk kernel
 (JPEG_AMD_BAND=1, kernels_band.hip), the register-prefetch luma kernel (JPEG_AMD_DIRECT=1), the part-pipelined launch
-(JPEG_AMD_OVERLAP=1), the persistent chroma kernel (JPEG_AMD_K1_PERSIST=1) and the 16-row encode tiles
-(JPEG_AMD_ENC_TY=16).  They were built to answer VERDICT r01's questions, measured slower than the default path
+(JPEG_AMD_OVERLAP=1), the persistent chroma kernel (JPEG_AMD_K1_PERSIST=1), the four-waves-per-SIMD luma kernel with the
+chroma tile inside the coefficient buffer (JPEG_AMD_ALIAS=1) and the 16-row encode tiles (JPEG_AMD_ENC_TY=16).  They were built to answer VERDICT r01's questions, measured slower than the default path
  and are kept switchable; the switches are read once per process, hence the child processes."""
 import os
 import subprocess
@@ -41,7 +41,7 @@ print("ok")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("switch", ["JPEG_AMD_BAND=1", "JPEG_AMD_DIRECT=1", "JPEG_AMD_OVERLAP=1", "JPEG_AMD_K1_PERSIST=1",
-                                    "JPEG_AMD_ENC_TY=16"])
+                                    "JPEG_AMD_ALIAS=1", "JPEG_AMD_ENC_TY=16"])
 def test_opt_in_path_matches_oracle(switch):
     k, v = switch.split("=")
     env = dict(os.environ)

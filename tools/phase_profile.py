@@ -25,14 +25,38 @@ for i in range(4): step(i & 1)
 torch.cuda.synchronize()
 ctx.timer_begin(); step(0); ms = ctx.timer_end()
 fn = lib.jpeg_amd_debug_phase_cycles; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_size_t]
-buf = np.zeros((3072, 8), np.uint64)
+buf = np.zeros((4096, 8), np.uint64)
 assert fn(buf.ctypes.data, buf.size) == 0
+buf = buf[buf[:, 6] > 0]   # waves that ran (3 072 at three waves per SIMD, 4 096 at four)
+print(f"{len(buf)} waves")
 names = ["wait coef DMA", "LDS coef read + chroma DMA issue", "IDCT", "chroma wait + next DMA issue", "hrow prologue + geometry", "8 pixel rows (colour, stage, store)"]
 tot = buf[:, :6].sum(axis=1).astype(np.float64)
 print(f"step {ms*1e3:.1f} us; per-wave total cycles mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(names):
     c = buf[:, i].astype(np.float64)
-    print(f"  {n:40s} {c.mean():10.0f} cycles/wave  {100*c.mean()/tot.mean():5.1f} %   per strip {c.mean()/(16384/3072):8.0f}")
+    print(f"  {n:40s} {c.mean():10.0f} cycles/wave  {100*c.mean()/tot.mean():5.1f} %   per strip {c.mean()/(16384/len(buf)):8.0f}")
 life, ticks = buf[:, 6].astype(np.float64), buf[:, 7].astype(np.float64)
 print(f"wave life: mean {life.mean():.0f} max {life.max():.0f} shader cycles = mean {ticks.mean() / 100:.1f} max {ticks.max() / 100:.1f} us of the 100 MHz counter"
       f" -> effective shader clock {100.0 * (life / ticks).mean():.0f} MHz while k_luma_fused runs")
+# per-wave placement and timing (start / end on the chip-wide 100 MHz counter, HW_ID, XCC_ID)
+fi = lib.jpeg_amd_debug_wave_info; fi.restype = C.c_int; fi.argtypes = [C.c_void_p, C.c_size_t]
+wi = np.zeros((4096, 4), np.uint64)
+if fi(wi.ctypes.data, wi.size) == 0:
+    wi = wi[:len(buf)].astype(np.int64)
+    t0 = wi[:, 0].min()
+    start, end = (wi[:, 0] - t0) / 100.0, (wi[:, 1] - t0) / 100.0
+    print(f"wave start: min {start.min():.1f} mean {start.mean():.1f} max {start.max():.1f} us; end: min {end.min():.1f} mean {end.mean():.1f} max {end.max():.1f} us")
+    print("end-time percentiles (us):", " ".join(f"{p}%={np.percentile(end, p):.1f}" for p in (1, 10, 25, 50, 75, 90, 99, 100)))
+    xcc = wi[:, 3]
+    for x in range(8):
+        m = xcc == x
+        if m.any():
+            print(f"  XCC {x}: {m.sum():5d} waves  start mean {start[m].mean():6.1f}  end mean {end[m].mean():6.1f} max {end[m].max():6.1f}  life mean {(end[m]-start[m]).mean():6.1f} min {(end[m]-start[m]).min():6.1f} max {(end[m]-start[m]).max():6.1f} us  clock {100.0*(life[m]/ticks[m]).mean():.0f} MHz")
+    hw = wi[:, 2]
+    cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+    print("HW_ID samples:", [hex(int(h)) for h in hw[:8]])
+    key = xcc * 1000 + se * 100 + sh * 16 + cu
+    ends_by_cu = {}
+    for k, e in zip(key, end): ends_by_cu.setdefault(int(k), []).append(e)
+    cu_end = np.array([max(v) for v in ends_by_cu.values()]); cu_n = np.array([len(v) for v in ends_by_cu.values()])
+    print(f"{len(cu_end)} distinct (xcc, se, sh, cu); waves per CU min {cu_n.min()} max {cu_n.max()}; last wave of a CU ends: min {cu_end.min():.1f} mean {cu_end.mean():.1f} max {cu_end.max():.1f} us")

@@ -27,6 +27,7 @@
 #include "kernels.hpp"
 
 #include <cstdlib>
+#include <utility>
 
 namespace jpeg_amd {
 
@@ -56,11 +57,44 @@ __device__ __forceinline__ float ubyte(uint32_t v)
 }
 
 // RGB.ycc -- jpeg.swift:463-478: x = ((m0 + m_r r) + m_g g) + m_b b, then clamp + truncate.
+// The two products by 0.5 are exact (r, b are bytes), so `x + 0.5 b` and `128 + 0.5 r` round once either way: those two
+// steps are one FMA each.  No other step may be fused: every other FMA placement changes some of the 2^24 results
+// (tests/test_colour_rounding.py enumerates them).
 __device__ __forceinline__ void rgb_to_ycc(float r, float g, float b, float &y, float &cb, float &cr)
 {
     y  = floorf((0.2990f * r + 0.5870f * g) + 0.1140f * b);          // `0 + x` is exact
-    cb = floorf(((128.0f + -0.1687f * r) + -0.3313f * g) + 0.5000f * b);
-    cr = floorf(((128.0f + 0.5000f * r) + -0.4187f * g) + -0.0813f * b);
+    cb = floorf(__builtin_fmaf(0.5000f, b, (128.0f + -0.1687f * r) + -0.3313f * g));
+    cr = floorf((__builtin_fmaf(0.5000f, r, 128.0f) + -0.4187f * g) + -0.0813f * b);
+}
+
+// horizontal frequency k of the coefficient at zigzag index z (inverse of zigzag_of over k), tabulated at compile time
+struct ColumnOfZigzag {
+    int k[64];
+    constexpr ColumnOfZigzag() : k{}
+    {
+        for (int kk = 0; kk < 8; ++kk)
+            for (int h = 0; h < 8; ++h) k[zigzag_of(kk, h)] = kk;
+    }
+};
+constexpr ColumnOfZigzag kColumnOfZigzag{};
+// the column after which the pair of zigzag slots (2m, 2m + 1) is complete
+template <int M>
+constexpr int pair_ready_after() { return kColumnOfZigzag.k[2 * M] > kColumnOfZigzag.k[2 * M + 1] ? kColumnOfZigzag.k[2 * M] : kColumnOfZigzag.k[2 * M + 1]; }
+
+template <int M>
+__device__ __forceinline__ void pack_pair_if_ready(const int (&ci)[64], uint32_t (&w)[32], int k)
+{
+    if (pair_ready_after<M>() == k) {   // k is a constant after unrolling
+        typedef short short2_t __attribute__((ext_vector_type(2)));
+        const short2_t pk = __builtin_amdgcn_cvt_pk_i16(ci[2 * M], ci[2 * M + 1]);   // |coefficient| < 2^15: never saturates
+        w[M] = __builtin_bit_cast(uint32_t, pk);
+        asm volatile("" : "+v"(w[M]));
+    }
+}
+template <int... M>
+__device__ __forceinline__ void pack_ready_pairs(const int (&ci)[64], uint32_t (&w)[32], int k, std::integer_sequence<int, M...>)
+{
+    (pack_pair_if_ready<M>(ci, w, k), ...);
 }
 
 // FDCT + quantise + zigzag scatter of one block held as 64 floats g[8y + x]; q / rq = modulated
@@ -90,9 +124,9 @@ __device__ __forceinline__ void fdct_quantise(const float (&g)[64], const float 
     // arithmetic of all eight columns around the table reads and needs > 200 VGPRs (spills).
 #pragma unroll
     for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(f[i]));
-    // w: 64 quantised coefficients, zigzag order, packed in pairs
-#pragma unroll
-    for (int m = 0; m < 32; ++m) w[m] = 0;
+    // w: 64 quantised coefficients, zigzag order, packed in pairs: a pair is packed by ONE v_cvt_pk_i16_i32 as soon as
+    // the later of its two columns is done (zigzag neighbours lie at most one column apart, so few integers wait)
+    int ci[64];   // by zigzag index
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         __builtin_amdgcn_sched_barrier(0);
@@ -106,12 +140,9 @@ __device__ __forceinline__ void fdct_quantise(const float (&g)[64], const float 
             const float y0 = res[h] * rr;
             const float e  = __builtin_fmaf(-y0, qq, res[h]);
             const float y1 = __builtin_fmaf(e, rr, y0);
-            const int ci = (int)(y1 + __builtin_copysignf(0.49999997f, y1));  // the cast truncates
-            const int z = zigzag_of(k, h);                                     // scatter (encode.swift:236-239)
-            if (z & 1) w[z >> 1] |= (uint32_t)ci << 16;
-            else w[z >> 1] |= (uint32_t)ci & 0xffffu;
-            asm volatile("" : "+v"(w[z >> 1]));
+            ci[zigzag_of(k, h)] = (int)(y1 + __builtin_copysignf(0.49999997f, y1));  // the cast truncates; scatter (encode.swift:236-239)
         }
+        pack_ready_pairs(ci, w, k, std::make_integer_sequence<int, 32>{});
     }
 }
 

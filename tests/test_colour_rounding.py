@@ -80,3 +80,29 @@ def test_green_two_fused_multiply_adds_every_input():
     assert np.array_equal(want, got)                  # the kernel's form: exact on all 2^24 triples
     other = _hw(np.floor(_fma(a, pb, _fma(b, pr, y + 0 * pr))))
     assert (other != want).any()                      # the other association is not
+
+
+def test_encode_matrix_only_the_exact_half_products_may_be_fused():
+    """k_encode_fused (kernels_encode.hip, rgb_to_ycc) evaluates RGB.ycc (jpeg.swift:463-478) op for op except for the two
+    steps whose product is exact -- 0.5 * b in Cb and 0.5 * r in Cr -- which are one FMA each.  All 2^24 (r, g, b):
+    those two placements give the reference's integer everywhere, every other FMA placement changes some result."""
+    LD = np.longdouble   # 64-bit significand: holds a 24 x 8-bit product plus a 24-bit addend of this range exactly
+
+    def fma(a, x, c):
+        return (LD(a) * x.astype(LD) + c.astype(LD)).astype(f32)
+
+    v = np.arange(256, dtype=f32)
+    r, g, b = (a.ravel() for a in np.meshgrid(v, v, v, indexing="ij"))
+    rows = {"y": (0.0, 0.2990, 0.5870, 0.1140), "cb": (128.0, -0.1687, -0.3313, 0.5), "cr": (128.0, 0.5, -0.4187, -0.0813)}
+    exact_placements = {"y": {(0, 0, 0), (1, 0, 0)}, "cb": {(0, 0, 0), (0, 0, 1)}, "cr": {(0, 0, 0), (1, 0, 0)}}
+    for name, (m0, mr, mg, mb) in rows.items():
+        m0, mr, mg, mb = f32(m0), f32(mr), f32(mg), f32(mb)
+        want = np.floor(((m0 + mr * r) + mg * g) + mb * b)
+        for s1 in (0, 1):
+            for s2 in (0, 1):
+                for s3 in (0, 1):
+                    x = fma(mr, r, np.full_like(r, m0)) if s1 else m0 + mr * r
+                    x = fma(mg, g, x) if s2 else x + mg * g
+                    x = fma(mb, b, x) if s3 else x + mb * b
+                    same = bool(np.array_equal(np.floor(x), want))
+                    assert same == ((s1, s2, s3) in exact_placements[name]), (name, s1, s2, s3)

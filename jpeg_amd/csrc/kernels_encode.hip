@@ -330,8 +330,11 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
                                 sum = crow[pl][y & 1][2 * i] + crow[pl][y & 1][2 * i + 1];
                             else
                                 sum = crow[pl][0][i] + crow[pl][1][i];
-                            // integer sum of <= 4 bytes, exact; Float(sum) / n truncated
-                            packed[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(sum * inv), i & 3, packed[i >> 2]);
+                            // integer sum of n <= 4 bytes, exact; Float(sum) / n truncated (encode.swift:419-421).  The
+                            // quotient is an integer plus 0, 1/n ... (n-1)/n: moved down by (1 - 1/n) / 2 it lies within
+                            // 3/8 of that integer and never on a tie, so the convert's round-to-nearest IS the truncation
+                            // (one exact FMA instead of a multiply and a floor)
+                            packed[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(sum, inv, -0.5f * (1.0f - inv)), i & 3, packed[i >> 2]);
                         }
                         uint32_t *row = sc + (pl * CH + (PERHALF ? lby0 : lby) * (8 / SY) + j) * CPITCH + lbx * (8 / SX) / 4;
 #pragma unroll
@@ -347,13 +350,17 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
         uint32_t pix[8][6];
         const bool inside = 8 * bx + 8 <= a.W && 8 * by + 8 <= a.H;
         if (FASTIN && inside) {
+            // scalar row base (the tile's first pixel row + y rows: SALU) + one 32-bit per-lane offset for all eight rows:
+            // no vector address arithmetic per row (it used to be three 64-bit multiply-adds per row)
+#ifdef JA_X_ENC_L2LOAD   // experiment: every block reads the image's first tile (L2 hits)
+            const uint8_t *tile0 = base;
+#else
+            const uint8_t *tile0 = base + ((size_t)(8 * tyi * TY) * a.W + (size_t)8 * txi * ETX) * 3;   // wave-uniform
+#endif
+            const uint32_t voff = ((uint32_t)(8 * lby) * (uint32_t)a.W + 8u * lbx) * 3u;   // < 64 rows x 65 535 px x 3 B
 #pragma unroll
             for (int y = 0; y < 8; ++y) {
-#ifdef JA_X_ENC_L2LOAD   // experiment: every block reads the image's first tile (L2 hits)
-                const uint2 *row = reinterpret_cast<const uint2 *>(base + ((size_t)(8 * lby + y) * a.W + 8 * lbx) * 3);
-#else
-                const uint2 *row = reinterpret_cast<const uint2 *>(base + ((size_t)(8 * by + y) * a.W + 8 * bx) * 3);
-#endif
+                const uint2 *row = reinterpret_cast<const uint2 *>(tile0 + (size_t)y * a.W * 3 + voff);
                 const uint2 p0 = row[0], p1 = row[1], p2 = row[2];
                 pix[y][0] = p0.x; pix[y][1] = p0.y; pix[y][2] = p1.x; pix[y][3] = p1.y; pix[y][4] = p2.x; pix[y][5] = p2.y;
             }

@@ -24,8 +24,9 @@
 //
 // Development switches (never defined in the product build; tools/build_exp.sh makes A/B builds,
 // DESIGN.md section 6 quotes the measurements): JA_PHASE_PROFILE (per-phase cycle counters,
-// tools/phase_profile.py), JA_X_NOIDCT / JA_X_NOSTORE (the kernel without its arithmetic / without
-// its stores), JA_X_SKIPK1 / JA_X_SKIPK2 (one launch of the pair only, tools/probe_overlap.py),
+// tools/phase_profile.py), JA_X_NOIDCT / JA_X_NOCOLOR / JA_X_NOSTORE / JA_X_NOCTILE (the kernel without its transform /
+// without its upsampling and colour arithmetic / without its stores / without the chroma tile copy: tools/ablate.sh),
+// JA_X_SKIPK1 / JA_X_SKIPK2 (one launch of the pair only, tools/probe_overlap.py),
 // JA_X_NO_IN420 / JA_X_FORCE_IN420 (4:2:0 chroma in the strip walk never / whenever the strips are wide),
 // JA_X_IN420_NT (its neighbour fetches with the `nt` hint: 8 % slower, they are re-used out of L2).
 #pragma clang fp contract(off)
@@ -743,7 +744,11 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         //      the replication a clamped COLUMN needs is patched in LDS on edge strips only. ----
         const int cx0 = sxi * CW, cy0 = syi * CR;
         const int pwd = a.pw_c >> 2;
+#ifdef JA_X_NOCTILE   // experiment: no copy of the chroma samples under the strip (what do those small reads cost?)
+        if constexpr (false) {
+#else
         if constexpr (CHROMA && !INSTRIP) {
+#endif
             // rows of a narrow tile are packed RPI to a transfer (the LDS image is lane-linear and the
             // tile rows are contiguous): 12 transfers instead of 36 for a 16 x 4 strip of 4:2:0
             constexpr int RPI = (ROWS % (64 / PITCH) == 0) ? 64 / PITCH : 1;
@@ -936,7 +941,14 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         for (int y = 0; y < 8; ++y) {  // pixel row y of every block row of the strip
             __builtin_amdgcn_sched_barrier(0);
             float cv[2][8];
+#ifdef JA_X_NOCOLOR   // experiment: the strip without the upsampling and colour arithmetic (memory operations and LDS traffic kept)
+            uint32_t dnc[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dnc[j] = __float_as_uint(yv[8 * y + j]) ^ rawn[j & 1][j % 3];
+            if constexpr (false) {
+#else
             if constexpr (CHROMA) {
+#endif
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
                     if constexpr (SY == 2) {
@@ -959,8 +971,15 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                 }
             }
             uint32_t d[6] = {0, 0, 0, 0, 0, 0};
+#ifdef JA_X_NOCOLOR
+#pragma unroll
+            for (int j = 0; j < 6; ++j) d[j] = dnc[j];
+#pragma unroll
+            for (int x = 0; x < 0; ++x) {
+#else
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
+#endif
                 const float yy = yv[8 * y + x];
                 float c0, c1, c2;
                 if constexpr (MODE == 1) {

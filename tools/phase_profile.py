@@ -21,7 +21,8 @@ def step(r):
     st = lib.jpeg_amd_decode_batch(ctx.handle, C.byref(L), 1, _lib.ptr_array([p[r].data_ptr() for p in planes]), strides,
                                    d_q.data_ptr(), 0, 2, 0, _lib.COLOR_RGB8, out[r].data_ptr(), W * H * 3)
     assert st == 0
-for i in range(4): step(i & 1)
+warm = int(sys.argv[1]) if len(sys.argv) > 1 else 4   # steps before the measured one (200: the power cap has bitten)
+for i in range(warm): step(i & 1)
 torch.cuda.synchronize()
 ctx.timer_begin(); step(0); ms = ctx.timer_end()
 fn = lib.jpeg_amd_debug_phase_cycles; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_size_t]

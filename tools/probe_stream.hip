@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
@@ -65,6 +66,29 @@ __global__ __launch_bounds__(256) void k_stream(const unsigned char *luma, const
         }
         unsigned char *base = out + (size_t)(8 * BH * ty) * pitch + (size_t)tx * ROWB;
         constexpr int CPR = ROWB / 16;             // 16-byte chunks per row
+        if constexpr (STORE == 2) {
+            // k_luma_fused's grouping: per pixel row y of every block row, the BH segments are BH * CPR = 96 chunks;
+            // a lane stores chunk `lane` and lanes 0..31 also chunk 64 + lane (two nt instructions per y)
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int u = 64 * k + lane, sg = u / CPR, j = u - CPR * sg;
+                    if (u < BH * CPR) __builtin_nontemporal_store(acc, (u4 *)(base + (size_t)(8 * sg + y) * pitch + 16 * j));
+                }
+            }
+            continue;
+        }
+        if constexpr (STORE == 3) {
+            // one instruction per row segment like STORE 1, but in the kernel's ORDER: pixel row y of every block row
+            // (rows y, y + 8, y + 16, ...), then y + 1 ...
+#pragma unroll
+            for (int y = 0; y < 8; ++y)
+#pragma unroll
+                for (int sg = 0; sg < BH; ++sg)
+                    if (lane < CPR) __builtin_nontemporal_store(acc, (u4 *)(base + (size_t)(8 * sg + y) * pitch + 16 * lane));
+            continue;
+        }
 #pragma unroll
         for (int y = 0; y < 8 * BH; ++y) {
 #pragma unroll
@@ -75,6 +99,56 @@ __global__ __launch_bounds__(256) void k_stream(const unsigned char *luma, const
                 }
             }
         }
+    }
+}
+
+
+// The fused kernel's SCHEDULE with plain coalesced loads: the next tile's 12 loads are issued BEFORE this tile's stores
+// (register prefetch, as k_luma_fused does with its coefficient buffer), the stores follow one pixel row at a time with an
+// LDS round trip in between (MODE bit 0), optionally with a pause of `gap` s_sleep units between rows (MODE bit 1).
+template <int BW, int BH, int MODE>
+__global__ __launch_bounds__(256) void k_sched(const unsigned char *luma, const unsigned char *chroma, unsigned char *out)
+{
+    __shared__ __attribute__((aligned(16))) u4 stage[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * 4;
+    constexpr int TX = UX / BW, TY = UY / BH, RUN = BW * 128, CH = BW * BH * 64, ROWB = BW * 24, CPR = ROWB / 16;
+    constexpr int NL = (BH * RUN + CH) / 1024;
+    const size_t pitch = (size_t)W * 3;
+    u4 nxt[NL];
+    auto fetch = [&](int t) {
+        const int ty = t / TX, tx = t - ty * TX;
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < BH; ++r) {
+            const unsigned char *src = luma + ((size_t)(ty * BH + r) * UX + (size_t)tx * BW) * 128;
+#pragma unroll
+            for (int o = 0; o < RUN; o += 1024) nxt[k++] = *(const u4 *)(src + o + 16 * lane);
+        }
+        const unsigned char *csrc = chroma + (size_t)t * CH;
+#pragma unroll
+        for (int o = 0; o < CH; o += 1024) nxt[k++] = *(const u4 *)(csrc + o + 16 * lane);
+    };
+    int t = blockIdx.x * 4 + wave;
+    if (t >= TX * TY) return;
+    fetch(t);
+    for (; t < TX * TY; t += nwaves) {
+        const int ty = t / TX, tx = t - ty * TX;
+        u4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < NL; ++k) acc ^= nxt[k];
+        if (!(MODE & 8)) { if (t + nwaves < TX * TY) fetch(t + nwaves); }
+        unsigned char *base = out + (size_t)(8 * BH * ty) * pitch + (size_t)tx * ROWB;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            if (MODE & 1) { stage[wave][lane] = acc; acc = stage[wave][lane ^ 1]; }
+#pragma unroll
+            for (int sg = 0; sg < BH; ++sg)
+                if (lane < CPR) __builtin_nontemporal_store(acc, (u4 *)(base + (size_t)(8 * sg + y) * pitch + 16 * lane));
+            if (MODE & 2) __builtin_amdgcn_s_sleep(8);
+        }
+        if (MODE & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain: this tile's stores (and the prefetch) before going on
+        if (MODE & 8) { if (t + nwaves < TX * TY) fetch(t + nwaves); }    // the prefetch issued AFTER the stores instead of before
     }
 }
 
@@ -95,14 +169,21 @@ int main(int argc, char **argv)
     std::vector<Variant> vs = {
         V(32, 2, 0, 1), V(32, 2, 2, 1), V(32, 2, 1, 1), V(32, 2, 2, 0), V(32, 2, 0, 0),
         V(64, 1, 0, 1), V(64, 1, 2, 1), V(64, 2, 0, 1), V(64, 2, 2, 1),
-        V(16, 4, 0, 1), V(16, 4, 2, 1), V(128, 1, 0, 1), V(32, 4, 0, 1), V(32, 1, 0, 1), V(32, 1, 2, 1)};
+        V(16, 4, 0, 1), V(16, 4, 2, 1), V(128, 1, 0, 1), V(32, 4, 0, 1), V(32, 1, 0, 1), V(32, 1, 2, 1),
+        V(16, 4, 0, 2), V(32, 2, 0, 2), V(16, 4, 2, 2), V(32, 2, 2, 2), V(16, 4, 0, 0),
+        V(16, 4, 0, 3), V(32, 2, 0, 3), V(16, 4, 2, 3), V(8, 8, 0, 1), V(16, 8, 0, 1), V(16, 2, 0, 1),
+        {"sched 16x4 prefetch", k_sched<16, 4, 0>}, {"sched 16x4 prefetch+lds", k_sched<16, 4, 1>}, {"sched 16x4 prefetch+lds+sleep", k_sched<16, 4, 3>},
+        {"sched 32x2 prefetch", k_sched<32, 2, 0>}, {"sched 32x2 prefetch+lds", k_sched<32, 2, 1>},
+        {"sched 16x4 prefetch+drain", k_sched<16, 4, 4>}, {"sched 16x4 late prefetch", k_sched<16, 4, 8>}, {"sched 16x4 late prefetch+drain", k_sched<16, 4, 12>},
+        {"sched 32x2 prefetch+drain", k_sched<32, 2, 4>}, {"sched 32x2 late prefetch", k_sched<32, 2, 8>}};
     const int grids[] = {256, 512, 768, 1024, 1280, 1536, 2048, 3072};
     const double bytes = (double)(out_bytes + luma_bytes + chroma_bytes);
     printf("%-24s", "tile / flavour  \\  WGs");
     for (int g : grids) printf("%7d", g);
     printf("   (GB/s, 403 MB per pass; best of 3 x 16 passes over a ring of 8 buffer sets)\n");
     for (auto &v : vs) {
-        printf("%-24s", v.name);
+        if (argc > 1 && !strstr(v.name, argv[1])) continue;
+        printf("%-32s", v.name);
         for (int g : grids) {
             float best = 1e9f;
             for (int rep = 0; rep < 3; ++rep) {

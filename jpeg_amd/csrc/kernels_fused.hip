@@ -211,9 +211,10 @@ struct LumaArgs {
 // g + nwaves, ...  Lane l is block (l % BX, l / BX) of the strip (row-major).  Everything a wave touches in LDS is private to it: there is no workgroup barrier,
 // waves drift apart and their memory and arithmetic phases interleave on the SIMD.
 //
-// What bounds this kernel is how many waves are READY to issue, not HBM: one wave alone issues
-// a VALU instruction only every ~7 cycles, three ready waves saturate the SIMD
-// (tools/probe_mix.hip).  So the design keeps waves from parking:
+// What bounds this kernel is HBM at the rate the chip sustains for a 1 : 1 read / write stream (5.4-6.1 TB/s,
+// tools/probe_stream.hip; the kernel moves its bytes at 5.6); the arithmetic has to stay hidden
+// behind that with three waves per SIMD (one wave alone issues a VALU instruction only every ~7-9 cycles,
+// tools/probe_mix.hip).  So the design keeps waves from parking:
 //   - the 8 KiB of coefficients of the NEXT strip are fetched by LDS-DMA
 //     (global_load_lds_dwordx4) into the wave's LDS buffer while it works on the current one;
 //     no VGPRs are spent on the prefetch.  The LDS image is lane-linear (a DMA requirement);

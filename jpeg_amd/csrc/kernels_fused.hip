@@ -199,6 +199,13 @@ struct LumaArgs {
     size_t out_stride;
     int tiles_x, tiles_per_image;
     int first_tile, total_tiles;   // this launch walks strips [first_tile, total_tiles) of the call
+    // Batches: n_images > 0 gives image i to the workgroups with blockIdx.x % 8 == i % 8, i.e. to ONE XCD (workgroups
+    // are dealt to the eight XCDs round-robin; tools/probe_xcd.hip).  The halo rows and columns of a strip's chroma tile
+    // are the neighbouring strips' own samples: with all strips of an image on one XCD they are found in its L2 instead
+    // of being fetched again by up to eight of them (a 1080p batch fetches its chroma planes 3.3 times over).  The
+    // partition is a function of blockIdx.x alone: correct whatever the hardware does with it.  Opt-in (see
+    // xcd_images_enabled: fewer fetches, no faster).
+    int xcd_images;
 };
 
 // SX, SY: chroma subsampling per axis (1 or 2); MODE: 0 = YCbCr bytes, 1 = RGB bytes;
@@ -480,9 +487,20 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         }
     };
 
-    const int nwaves = gridDim.x * NW;
-    int s = a.first_tile + blockIdx.x * NW + wave;
-    if (s >= a.total_tiles) return;
+    // The wave's walk: elements k, k + stride, ... of a list of `len` strips.  One list for the launch (strip = first_tile + k),
+    // or one list per residue of blockIdx.x mod 8 (xcd_images: the strips of images x, x + 8, ... back to back).
+    const bool by_xcd = a.xcd_images > 0;
+    const int xcd = by_xcd ? (int)(blockIdx.x & 7u) : 0;
+    const int nwaves = by_xcd ? (int)(gridDim.x >> 3) * NW : (int)gridDim.x * NW;   // the walk's stride
+    const int len = by_xcd ? ((a.xcd_images - xcd + 7) >> 3) * a.tiles_per_image : a.total_tiles - a.first_tile;
+    auto strip_at = [&](int k) -> int {
+        if (!by_xcd) return a.first_tile + k;
+        const int q = k / a.tiles_per_image;
+        return (xcd + 8 * q) * a.tiles_per_image + (k - q * a.tiles_per_image);
+    };
+    int k = by_xcd ? (int)(blockIdx.x >> 3) * NW + wave : (int)blockIdx.x * NW + wave;
+    if (k >= len) return;
+    int s = strip_at(k);
     // DIRECT: the block of the NEXT strip this work-item transforms, requested while the current one is worked on
     uint32_t wn[DIRECT ? 32 : 1];
     auto fetch_block = [&](int st, int ln) {
@@ -507,7 +525,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     const unsigned long long t_first = t_prev, r_first = __builtin_amdgcn_s_memrealtime();   // shader cycles / 100 MHz ticks
 #endif
 
-    for (; s < a.total_tiles; s += nwaves) {
+    for (; k < len; k += nwaves, s = strip_at(min(k, len - 1))) {
         // Launder the lane id once per strip: everything below that depends only on the lane is
         // cheap to recompute, but hoisted out of this loop it would pin ~60 VGPRs for good.
         int lane = lane0;
@@ -547,7 +565,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         // few to keep it busy.  A wave with more strips left therefore runs at a higher priority: the laggards catch up
         // and all waves of a SIMD leave within a strip of each other (ends between 47 and 66 us).
         {
-            const int rem = (a.total_tiles - 1 - s) / nwaves;   // strips after this one
+            const int rem = (len - 1 - k) / nwaves;   // strips after this one
             if (rem >= 3) __builtin_amdgcn_s_setprio(3);
             else if (rem == 2) __builtin_amdgcn_s_setprio(2);
             else if (rem == 1) __builtin_amdgcn_s_setprio(1);
@@ -837,7 +855,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
         if constexpr (!DIRECT && !ALIAS) {
-            if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, INSTRIP ? 1 : 0);
+            if (k + nwaves < len) dma_strip(strip_at(k + nwaves), lane, INSTRIP ? 1 : 0);
         }
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
@@ -1022,7 +1040,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             //      dwords of the next patch row ----
             if (y > 0) store_row(y - 1);
             if constexpr (DIRECT) {
-                if (y == 4 && s + nwaves < a.total_tiles) fetch_block(s + nwaves, lane);
+                if (y == 4 && k + nwaves < len) fetch_block(strip_at(k + nwaves), lane);
             }
             uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
             sw[0] = make_uint2(d[0], d[1]);
@@ -1039,7 +1057,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                     if constexpr (ALIAS) {
                         if (y == 5) {   // the tile has been read for the last time: the next strip's coefficients may land on it
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (s + nwaves < a.total_tiles) dma_strip(s + nwaves, lane, 0);
+                            if (k + nwaves < len) dma_strip(strip_at(k + nwaves), lane, 0);
                         }
                     }
                 } else if (y < 7) {
@@ -1095,6 +1113,16 @@ inline bool direct_420()
     return v;
 }
 
+// development switch: JPEG_AMD_XCD_IMAGES=1 gives every image of a batch to one XCD (LumaArgs::xcd_images).  OFF by default:
+// it does what it was built for -- k_luma_fused's FETCH_SIZE for 512 x 1080p drops from 3.30 to 2.71 GB, the chroma planes
+// are fetched 1.1 instead of 3.3 times (tools/pmc_xcd.sh) -- and the batch takes 1 511 instead of 1 488 us: the repeated
+// fetches were served by the Infinity Cache, not by HBM, and cost nothing that matters.
+inline bool xcd_images_enabled()
+{
+    static const bool v = [] { const char *e = std::getenv("JPEG_AMD_XCD_IMAGES"); return e && e[0] == '1'; }();
+    return v;
+}
+
 // development switch: JPEG_AMD_ALIAS=1 selects the four-waves-per-SIMD 4:2:0 luma kernel whose chroma tile lives inside the
 // coefficient buffer.  OFF by default: bit-identical and no faster in sustained runs (tools/ab_band.py --env=JPEG_AMD_ALIAS:
 // 102.2 vs 103.1 us at 8192 x 8192, 1 470 vs 1 478 us for 512 x 1080p) -- its waves advance 4/3 slower and the shader
@@ -1108,30 +1136,22 @@ inline bool alias_420()
 template <int MODE, bool FAST, int BX>
 hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, int sy, bool chroma)
 {
-#define JA_K(SX_, SY_, CH_)                                                          \
-    {                                                                                \
-        auto k = k_luma_fused<SX_, SY_, MODE, CH_, FAST, BX>;                        \
-        const int cap = resident_workgroups<SX_, SY_, MODE, CH_, FAST, BX>();        \
-        hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a); \
-    }
+    // grid = min(work, resident capacity); the per-XCD image partition needs the full, 8-divisible grid
+    auto go = [&](auto kernel, int cap) {
+        LumaArgs b = a;
+        const int grid = wgs < cap ? wgs : cap;
+        if (grid != cap || (grid & 7) != 0) b.xcd_images = 0;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, stream, b);
+    };
+#define JA_K(SX_, SY_, CH_) go(k_luma_fused<SX_, SY_, MODE, CH_, FAST, BX>, resident_workgroups<SX_, SY_, MODE, CH_, FAST, BX>());
     if (!chroma) JA_K(1, 1, false)
     else if (sx == 2 && sy == 2 && a.ccoef[0] != nullptr) {   // chroma transformed in the strip walk (IN420)
-        if constexpr (BX == 32) {
-            auto k = k_luma_fused<2, 2, MODE, true, FAST, 32, true>;
-            const int cap = resident_workgroups<2, 2, MODE, true, FAST, 32, true>();
-            hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a);
-        }
+        if constexpr (BX == 32) go(k_luma_fused<2, 2, MODE, true, FAST, 32, true>, resident_workgroups<2, 2, MODE, true, FAST, 32, true>());
     }
-    else if (sx == 2 && sy == 2 && direct_420()) {
-        auto k = k_luma_fused<2, 2, MODE, true, FAST, BX, false, true>;
-        const int cap = resident_workgroups<2, 2, MODE, true, FAST, BX, false, true>();
-        hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a);
-    }
-    else if (sx == 2 && sy == 2 && alias_420()) {
-        auto k = k_luma_fused<2, 2, MODE, true, FAST, BX, false, false, true>;
-        const int cap = resident_workgroups<2, 2, MODE, true, FAST, BX, false, false, true>();
-        hipLaunchKernelGGL(k, dim3(wgs < cap ? wgs : cap), dim3(kThreads), 0, stream, a);
-    }
+    else if (sx == 2 && sy == 2 && direct_420())
+        go(k_luma_fused<2, 2, MODE, true, FAST, BX, false, true>, resident_workgroups<2, 2, MODE, true, FAST, BX, false, true>());
+    else if (sx == 2 && sy == 2 && alias_420())
+        go(k_luma_fused<2, 2, MODE, true, FAST, BX, false, false, true>, resident_workgroups<2, 2, MODE, true, FAST, BX, false, false, true>());
     else if (sx == 2 && sy == 2) JA_K(2, 2, true)
     else if (sx == 2 && sy == 1) JA_K(2, 1, true)
     else if (sx == 1 && sy == 2) JA_K(1, 2, true)
@@ -1359,6 +1379,8 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
             const hipError_t e = launch_chroma(stream, 0, n_images, 0, ca.end_block);
             if (e != hipSuccess) return e;
         }
+        // (opt-in) batches of subsampled images: each image's strips on one XCD, see LumaArgs::xcd_images
+        if (chroma && n_images >= 32 && xcd_images_enabled()) la.xcd_images = n_images;
         return launch_strips(stream, 0, la.total_tiles);
     }
 

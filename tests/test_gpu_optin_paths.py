@@ -1,6 +1,7 @@
 """The opt-in variants of the fused 4:2:0 decode stay bit-identical to the oracle: the band-walk kernel
 (JPEG_AMD_BAND=1, kernels_band.hip), the register-prefetch luma kernel (JPEG_AMD_DIRECT=1), the part-pipelined launch
-(JPEG_AMD_OVERLAP=1), the persistent chroma kernel (JPEG_AMD_K1_PERSIST=1), the four-waves-per-SIMD luma kernel with the
+(JPEG_AMD_OVERLAP=1), the persistent chroma kernel (JPEG_AMD_K1_PERSIST=1), the per-XCD image partition of batches
+(JPEG_AMD_XCD_IMAGES=1), the four-waves-per-SIMD luma kernel with the
 chroma tile inside the coefficient buffer (JPEG_AMD_ALIAS=1) and the 16-row encode tiles (JPEG_AMD_ENC_TY=16).  They were built to answer VERDICT r01's questions, measured slower than the default path
  and are kept switchable; the switches are read once per process, hence the child processes."""
 import os
@@ -50,3 +51,14 @@ def test_opt_in_path_matches_oracle(switch):
         env["JA_TEST_BIG"] = "1"
     p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_batch_with_every_image_on_one_xcd_matches_oracle():
+    """JPEG_AMD_XCD_IMAGES=1 (k_luma_fused walks one strip list per residue of blockIdx.x mod 8) only engages for batches of
+    32 images or more that fill the resident grid: run the 64 x 1080p slice of config 5 under it."""
+    env = dict(os.environ)
+    env["JPEG_AMD_XCD_IMAGES"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_full_size.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "config5"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]

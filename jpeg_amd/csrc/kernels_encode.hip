@@ -248,13 +248,26 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
     uint32_t *stage = stage_all[threadIdx.x >> 6];
     uint32_t *stash = stash_all[(CHROMA && INTHREAD) ? threadIdx.x >> 6 : 0];
 
-    if (threadIdx.x < 192 && (CHROMA || threadIdx.x < 64)) {
-        const int t = threadIdx.x >> 6, k = threadIdx.x & 7, h = (threadIdx.x >> 3) & 7;
-        const float qv = modulate_entry(k, h, 8.0f, a.quanta[img * a.quanta_stride + 64 * a.qi[t] + zigzag_of(k, h)]);
-        sq[t][8 * k + h] = qv;                 // transposed: [k][h]
-        sr[t][8 * k + h] = 1.0f / qv;          // IEEE division: RN(1 / q)
-    }
-    __syncthreads();
+    // The tables are first needed by the luma FDCT.  Their quantum is REQUESTED here and turned into table entries only
+    // after the tile's pixel loads have been issued, barrier included.  (Table first, barrier, then the pixel loads put two
+    // memory latencies in a row at the head of every workgroup; a barrier later, in front of the FDCT, re-aligns the four
+    // waves in the middle of their work: 4:2:0 23.5 -> 26.3 us.)
+    // Measured (profiles/r02_ab_encode_tables_first.txt): -1.5 to -2 us for the 16-row tiles (4:2:2 30.3 -> 28.5, 4:4:4 37.0 ->
+    // 35.0 us at 4096 x 4096), but +2.5 us for the 8-row tiles of grey and 4:2:0, whose single round of workgroups then
+    // requests the whole frame in the same instant -- those keep the table in front (TABLES_LATE = false).
+    constexpr bool TABLES_LATE = TY == 16;
+    const bool qthread = threadIdx.x < 192 && (CHROMA || threadIdx.x < 64);
+    const int qt = threadIdx.x >> 6, qk = threadIdx.x & 7, qh = (threadIdx.x >> 3) & 7;
+    uint16_t qraw = 1;
+    if (qthread) qraw = a.quanta[img * a.quanta_stride + 64 * a.qi[qt] + zigzag_of(qk, qh)];
+    auto publish_tables = [&]() {
+        if (qthread) {
+            const float qv = modulate_entry(qk, qh, 8.0f, qraw);
+            sq[qt][8 * qk + qh] = qv;                 // transposed: [k][h]
+            sr[qt][8 * qk + qh] = 1.0f / qv;          // IEEE division: RN(1 / q)
+        }
+    };
+    if constexpr (!TABLES_LATE) { publish_tables(); __syncthreads(); }
 
     // chroma blocks of the tile (or of one half of it) from the pooled LDS tile
     auto chroma_blocks = [&](int half) {
@@ -382,6 +395,7 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
                 }
             }
         }
+        if (TABLES_LATE && half == 0) { publish_tables(); __syncthreads(); }   // the pixel loads are in flight: the barrier waits under them
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
             __builtin_amdgcn_sched_barrier(0);

@@ -64,23 +64,26 @@ __global__ __launch_bounds__(kThreads) void k_chroma_idct(ChromaArgs a)
 {
     __shared__ float sq[64];
     const int img = blockIdx.y, pl = blockIdx.z;
-    if (threadIdx.x < 64) {
-        const int k = threadIdx.x & 7, h = threadIdx.x >> 3;
-        sq[threadIdx.x] = modulate_entry(k, h, 0.125f,
-                                         a.quanta[img * a.quanta_stride + 64 * a.qi[pl] + zigzag_of(k, h)]);
-    }
-    __syncthreads();
+    // the table's quantum is requested first, the block's coefficients right behind it: one memory latency at the head of
+    // the workgroup instead of two (table, barrier, then the coefficient loads)
+    const int qk = threadIdx.x & 7, qh = (threadIdx.x >> 3) & 7;
+    uint16_t qraw = 1;
+    if (threadIdx.x < 64) qraw = a.quanta[img * a.quanta_stride + 64 * a.qi[pl] + zigzag_of(qk, qh)];
     const int b = a.first_block + blockIdx.x * kThreads + threadIdx.x;
-    if (b >= a.end_block) return;
-    const int by = b / a.ux, bx = b - by * a.ux;
+    const bool mine = b < a.end_block;
+    const int bc = mine ? b : a.end_block - 1;   // work-items past the range re-read the last block and store nothing
+    const int by = bc / a.ux, bx = bc - by * a.ux;
 
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.coef[pl] + img * a.coef_stride[pl] + (size_t)64 * b);
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.coef[pl] + img * a.coef_stride[pl] + (size_t)64 * bc);
     uint32_t w[32];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const uint4 v = src[i];
         w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
     }
+    if (threadIdx.x < 64) sq[threadIdx.x] = modulate_entry(qk, qh, 0.125f, qraw);
+    __syncthreads();
+    if (!mine) return;
     float g[64];
     idct_block(w, sq, 128.5f, g);  // level = 2^(P-1) + 0.5, P = 8
 

@@ -68,7 +68,10 @@ def sha16(paths):
 try:
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
-    commit = os.environ.get("JPEG_AMD_COMMIT", "unknown (no .git on the GPU box; see the commit that adds this file)")
+    # the GPU box has no .git: `git rev-parse --short HEAD > .commit_stamp` before the gpurun call carries the commit over
+    stamp = os.path.join(ROOT, ".commit_stamp")
+    commit = os.environ.get("JPEG_AMD_COMMIT") or (open(stamp).read().strip() + " (+ working tree at profiling time)" if os.path.exists(stamp)
+                                                   else "unknown (no .git on the GPU box; see the commit that adds this file)")
 print(json.dumps({
     "tag": tag, "commit": commit,
     "kernel_source_sha16": sha16(["jpeg_amd/csrc/" + f for f in ("kernels_fused.hip", "dct.hpp", "upsample.hpp", "kernels.hpp")]),

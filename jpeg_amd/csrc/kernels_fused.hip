@@ -209,6 +209,7 @@ struct LumaArgs {
     // partition is a function of blockIdx.x alone: correct whatever the hardware does with it.  Opt-in (see
     // xcd_images_enabled: fewer fetches, no faster).
     int xcd_images;
+    int quad;                // 4:2:0 in one launch, four stacked strips per workgroup sharing a chroma tile (k_luma_fused QUAD)
 };
 
 // SX, SY: chroma subsampling per axis (1 or 2); MODE: 0 = YCbCr bytes, 1 = RGB bytes;
@@ -292,9 +293,16 @@ __device__ unsigned long long g_wave_info[4096 * 4];   // start tick, end tick (
 template <int SX, int SY, bool CHROMA, bool DIRECT, bool ALIAS = false>
 constexpr int luma_waves_per_simd() { return ALIAS ? 4 : (CHROMA && (SX == 1 || SY == 1)) ? 2 : 3; }
 
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false, bool ALIAS = false>
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false, bool ALIAS = false, bool QUAD_ = false>
 __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRECT, ALIAS>())) void k_luma_fused(LumaArgs a)
 {
+    // QUAD (4:2:0 in one launch, opt-in JPEG_AMD_QUAD=1): the four waves of a workgroup take four vertically stacked
+    // strips and SHARE one chroma tile in LDS.  Each wave transforms, in ONE pass, the 32 chroma blocks under its own strip,
+    // a quarter of the 64 blocks that supply the sample rows above and below the stack, and the side blocks of its row
+    // (56 work-items busy); after a barrier every wave finds its halo rows in its neighbours' samples.  2.0 IDCT passes
+    // per strip where STRIP420 needs 2.7 (44 + 64 work-items, the second pass at two thirds of the arithmetic) and the
+    // two launches 1.5 -- and no chroma samples through HBM.
+    constexpr bool QUAD = QUAD_ && STRIP420 && CHROMA && SX == 2 && SY == 2 && BX == 32;
     // ALIAS (two-launch 4:2:0): the chroma tile lives INSIDE the wave's coefficient buffer.  The buffer is only needed
     // from the prefetch of the next strip's coefficients to their read-back at the top of that strip, the tile from
     // there to the last chroma read of the pixel rows (row 5) -- so the prefetch is issued after row 5 instead of
@@ -323,7 +331,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     // transforms the Cb and Cr blocks that lie under its luma block itself (same geometry), parks
     // their samples as bytes in LDS ([dword][lane], like k_encode_fused) and then does the luma block
     constexpr bool INTHREAD = CHROMA && SX == 1 && SY == 1;
-    constexpr int PLANE = (CHROMA && !INTHREAD) ? ROWS * PITCH : 1;
+    constexpr int QROWS = 4 * CR + 2;                    // QUAD: sample rows of the shared tile (halo, 4 x 8 rows, halo)
+    constexpr int PLANE = QUAD ? QROWS * PITCH : (CHROMA && !INTHREAD) ? ROWS * PITCH : 1;   // dwords per plane of the tile
     constexpr int SEG_DW = BX * 6;                       // one pixel row of one block row: 24 B per block
     constexpr int CPS = SEG_DW / 4;                      // 16-byte chunks per such segment
     // 4:2:2 (wide strips): the 16 x 2 chroma blocks per plane under a strip are exactly one block per
@@ -348,7 +357,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][DIRECT ? 4 : 64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     static_assert(!ALIAS || 2 * PLANE <= 64 * 32, "the chroma tile must fit the coefficient buffer");
-    __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : ALIAS ? 1 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
+    __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : (ALIAS || QUAD) ? 1 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
+    __shared__ uint32_t qtile[QUAD ? 2 * PLANE : 1];     // QUAD: the workgroup's tile; wave w's window starts at sample row 8 w
     __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
 
     const int lane0 = threadIdx.x & 63;
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     // LDS byte address of the wave's coefficient buffer (low 32 bits of the flat shared address)
     const uint32_t coef_lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)coef_w);
-    uint32_t *sc = ALIAS ? coef_w : scw[wave];
+    uint32_t *sc = ALIAS ? coef_w : QUAD ? qtile + 8 * wave * PITCH : scw[wave];
     const uint32_t sc_lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sc);
     float *sq = sqw[wave][0];
@@ -380,6 +390,31 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         const int16_t *base = a.coef + img * a.coef_stride;
         if constexpr (INTHREAD) {
             if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
+        }
+        if constexpr (QUAD) {
+            if (which == 3) {
+                // the wave's chroma pass.  Block b (= the work-item that transforms it):
+                //   0..31  plane b >> 4, column b & 15 of the wave's own chroma block row (= its strip row syi)
+                //   32..47 column b & 15 of the row above the stack (waves 0, 1: plane = wave) or below it (waves 2, 3: plane = wave - 2)
+                //   48..51 the own row's neighbours: plane (b >> 1) & 1, side b & 1 (0: column 16 sxi - 1, 1: column 16 sxi + 16)
+                //   52..55 the same two columns of the row above (wave 0) / below (wave 3) the stack: the tile's corner samples
+                const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
+                const int top = syi - wave;   // first strip row of the stack
+                const int halo_row = min(max(wave < 2 ? top - 1 : top + NW, 0), uyc - 1);   // missing rows: fetched, not used
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const int b = 8 * i + (lane >> 3);
+                    int pl, bx, by;
+                    if (i < 4) { pl = i >> 1; bx = 16 * sxi + (b & 15); by = syi; }
+                    else if (i < 6) { pl = wave & 1; bx = 16 * sxi + (b & 15); by = halo_row; }
+                    else { pl = (b >> 1) & 1; bx = (b & 1) ? 16 * sxi + 16 : 16 * sxi - 1; by = b < 52 ? syi : halo_row; }
+                    const int16_t *cbase = a.ccoef[pl] + img * a.ccoef_stride[pl];
+                    const uint32_t blk = (bx >= 0 && bx < uxc) ? (uint32_t)by * uxc + bx : 0u;
+                    const int c = (lane & 7) ^ ((b >> 1) & 7);
+                    lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+                }
+                return;
+            }
         }
         if constexpr (IN420) {
             const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
@@ -492,16 +527,25 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 
     // The wave's walk: elements k, k + stride, ... of a list of `len` strips.  One list for the launch (strip = first_tile + k),
     // or one list per residue of blockIdx.x mod 8 (xcd_images: the strips of images x, x + 8, ... back to back).
-    const bool by_xcd = a.xcd_images > 0;
+    // QUAD: the WORKGROUP walks stacks of four strips (the host only selects it when every image is a whole number of
+    // stacks); wave w takes strip row 4 R + w of stack (R, column c).  All four waves make the same number of trips:
+    // the barriers inside the loop are met by everyone.
+    const bool by_xcd = !QUAD && a.xcd_images > 0;
     const int xcd = by_xcd ? (int)(blockIdx.x & 7u) : 0;
-    const int nwaves = by_xcd ? (int)(gridDim.x >> 3) * NW : (int)gridDim.x * NW;   // the walk's stride
-    const int len = by_xcd ? ((a.xcd_images - xcd + 7) >> 3) * a.tiles_per_image : a.total_tiles - a.first_tile;
+    const int nwaves = QUAD ? (int)gridDim.x : by_xcd ? (int)(gridDim.x >> 3) * NW : (int)gridDim.x * NW;   // the walk's stride
+    const int len = QUAD ? a.total_tiles / NW : by_xcd ? ((a.xcd_images - xcd + 7) >> 3) * a.tiles_per_image : a.total_tiles - a.first_tile;
     auto strip_at = [&](int k) -> int {
+        if constexpr (QUAD) {
+            const int per_image = a.tiles_per_image / NW;
+            const int im = k / per_image, rem = k - im * per_image;
+            const int R = rem / a.tiles_x, c = rem - R * a.tiles_x;
+            return im * a.tiles_per_image + (NW * R + wave) * a.tiles_x + c;
+        }
         if (!by_xcd) return a.first_tile + k;
         const int q = k / a.tiles_per_image;
         return (xcd + 8 * q) * a.tiles_per_image + (k - q * a.tiles_per_image);
     };
-    int k = by_xcd ? (int)(blockIdx.x >> 3) * NW + wave : (int)blockIdx.x * NW + wave;
+    int k = QUAD ? (int)blockIdx.x : by_xcd ? (int)(blockIdx.x >> 3) * NW + wave : (int)blockIdx.x * NW + wave;
     if (k >= len) return;
     int s = strip_at(k);
     // DIRECT: the block of the NEXT strip this work-item transforms, requested while the current one is worked on
@@ -519,7 +563,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         }
     };
     if constexpr (DIRECT) fetch_block(s, lane0);
-    else dma_strip(s, lane0, INSTRIP ? 1 : 0);
+    else dma_strip(s, lane0, QUAD ? 3 : INSTRIP ? 1 : 0);
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
 #ifdef JA_PHASE_PROFILE
@@ -619,7 +663,89 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             }
         }
 
-        if constexpr (IN420) {
+        if constexpr (QUAD) {
+            const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
+            const int top = syi - wave;
+            const bool stack_above = top > 0, stack_below = top + NW < uyc;   // workgroup-uniform
+            const bool has_left = sxi > 0, has_right = 16 * sxi + 16 < uxc;
+            auto pack4 = [](const float *v) -> uint32_t {
+                uint32_t d = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d = __builtin_amdgcn_cvt_pk_u8_f32(floorf(v[i]), i, d);
+                return d;
+            };
+            auto rep1 = [](float v) -> uint32_t { return __builtin_amdgcn_cvt_pk_u8_f32(floorf(v), 0, 0u) * 0x01010101u; };
+            // w holds the chroma pass's block (read at the top); the luma blocks of the strip follow it into the buffer
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_strip(s, lane, 0);
+            {
+                const int pl = lane < 32 ? lane >> 4 : lane < 48 ? (wave & 1) : (lane >> 1) & 1;
+                float g[64];
+                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                // everyone has read the previous stack's tile before anyone overwrites it -- met HERE, after the transform, so
+                // that a wave that finished its pixel rows early spends the wait on the next stack's transform instead
+#ifndef JA_X_QUAD_B2_END
+#pragma unroll
+                for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(g[i]));
+                __syncthreads();
+#endif
+                uint32_t *tile = qtile + pl * PLANE;       // row 0: halo above the stack; rows 1 + 8 w ...: wave w; row QROWS - 1: halo below
+                if (lane < 32) {
+                    uint32_t *dst = tile + (1 + 8 * wave) * PITCH + 1 + 2 * (lane & 15);
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) {
+                        dst[y * PITCH] = pack4(&g[8 * y]);
+                        dst[y * PITCH + 1] = pack4(&g[8 * y + 4]);
+                    }
+                } else if (lane < 48) {
+                    if (wave < 2 ? stack_above : stack_below) {
+                        uint32_t *dst = tile + (wave < 2 ? 0 : QROWS - 1) * PITCH + 1 + 2 * (lane & 15);
+                        const float *row = wave < 2 ? &g[56] : &g[0];   // last row of the block above / first row of the block below
+                        dst[0] = pack4(row);
+                        dst[1] = pack4(row + 4);
+                    }
+                } else if (lane < 56) {
+                    const int side = lane & 1;
+                    if (side ? has_right : has_left) {
+                        uint32_t *col = tile + (side ? PITCH - 1 : 0);
+                        if (lane < 52) {
+#pragma unroll
+                            for (int y = 0; y < 8; ++y) col[(1 + 8 * wave + y) * PITCH] = rep1(side ? g[8 * y] : g[8 * y + 7]);
+                        } else if (wave == 0 && stack_above) col[0] = rep1(side ? g[56] : g[63]);
+                        else if (wave == NW - 1 && stack_below) col[(QROWS - 1) * PITCH] = rep1(side ? g[0] : g[7]);
+                    }
+                }
+            }
+            // the plane's left / right edge: the reference clamps the sample index (decode.swift:4245) -- own rows here,
+            // the two halo rows after the barrier (their samples come from other waves)
+            if (!has_left || !has_right) {
+                if (lane < 16) {
+                    uint32_t *row = qtile + (lane >> 3) * PLANE + (1 + 8 * wave + (lane & 7)) * PITCH;
+                    if (!has_left) row[0] = (row[1] & 0xffu) * 0x01010101u;
+                    if (!has_right) row[PITCH - 1] = (row[PITCH - 2] >> 24) * 0x01010101u;
+                }
+            }
+            __syncthreads();   // the tile is complete (all four waves' samples)
+            if (wave == 0 || wave == NW - 1) {
+                // image top / bottom: a missing row is the nearest own row (decode.swift:4246); then its two edge columns
+                const int hr = wave == 0 ? 0 : QROWS - 1, src = wave == 0 ? 1 : QROWS - 2;
+                const bool missing = wave == 0 ? !stack_above : !stack_below;
+                if (missing) {
+                    for (int d = lane; d < 2 * PITCH; d += 64) {
+                        uint32_t *col = qtile + (d >= PITCH ? PLANE + d - PITCH : d);
+                        col[hr * PITCH] = col[src * PITCH];
+                    }
+                } else if ((!has_left || !has_right) && lane < 2) {
+                    uint32_t *row = qtile + lane * PLANE + hr * PITCH;
+                    if (!has_left) row[0] = (row[1] & 0xffu) * 0x01010101u;
+                    if (!has_right) row[PITCH - 1] = (row[PITCH - 2] >> 24) * 0x01010101u;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_block();
+        }
+        if constexpr (IN420 && !QUAD) {
             const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
             const bool has_above = syi > 0, has_below = syi + 1 < uyc;        // wave-uniform
             const bool has_left = sxi > 0, has_right = 16 * sxi + 16 < uxc;
@@ -858,7 +984,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
         if constexpr (!DIRECT && !ALIAS) {
-            if (k + nwaves < len) dma_strip(strip_at(k + nwaves), lane, INSTRIP ? 1 : 0);
+            if (k + nwaves < len) dma_strip(strip_at(k + nwaves), lane, QUAD ? 3 : INSTRIP ? 1 : 0);
         }
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
@@ -1071,6 +1197,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         }
         __builtin_amdgcn_sched_barrier(0);
         store_row(7);
+#ifdef JA_X_QUAD_B2_END
+        if constexpr (QUAD) __syncthreads();
+#endif
         JA_PHASE(5)
     }
 #ifdef JA_PHASE_PROFILE
@@ -1094,12 +1223,12 @@ inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kT
 
 // Persistent grid = what is resident at once: workgroups per CU (LDS- and VGPR-bound, differs per
 // instantiation: 3 for 4:2:0 and grey, 2 for the variants with a full-width chroma tile) x CUs.
-template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false, bool ALIAS = false>
+template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX, bool STRIP420 = false, bool DIRECT = false, bool ALIAS = false, bool QUAD = false>
 int resident_workgroups()
 {
     static int cached = 0;  // one per instantiation
     if (cached == 0) {
-        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX, STRIP420, DIRECT, ALIAS>;
+        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX, STRIP420, DIRECT, ALIAS, QUAD>;
         int per_cu = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1113,6 +1242,14 @@ int resident_workgroups()
 inline bool direct_420()
 {
     static const bool v = [] { const char *e = std::getenv("JPEG_AMD_DIRECT"); return e && e[0] == '1'; }();
+    return v;
+}
+
+// JPEG_AMD_QUAD=0: 4:2:0 images that are a whole number of 256 x 64-pixel stacks take the two launches (or STRIP420) like
+// every other image instead of k_luma_fused's QUAD walk (one launch, the four waves of a workgroup sharing a chroma tile)
+inline bool quad_enabled()
+{
+    static const bool v = [] { const char *e = std::getenv("JPEG_AMD_QUAD"); return !(e && e[0] == '0'); }();
     return v;
 }
 
@@ -1148,7 +1285,13 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
     };
 #define JA_K(SX_, SY_, CH_) go(k_luma_fused<SX_, SY_, MODE, CH_, FAST, BX>, resident_workgroups<SX_, SY_, MODE, CH_, FAST, BX>());
     if (!chroma) JA_K(1, 1, false)
-    else if (sx == 2 && sy == 2 && a.ccoef[0] != nullptr) {   // chroma transformed in the strip walk (IN420)
+    else if (sx == 2 && sy == 2 && a.ccoef[0] != nullptr) {   // chroma transformed in the strip walk (IN420 / QUAD)
+        if constexpr (BX == 32 && FAST) {
+            if (a.quad) {
+                go(k_luma_fused<2, 2, MODE, true, FAST, 32, true, false, false, true>, resident_workgroups<2, 2, MODE, true, FAST, 32, true, false, false, true>());
+                return hipGetLastError();
+            }
+        }
         if constexpr (BX == 32) go(k_luma_fused<2, 2, MODE, true, FAST, 32, true>, resident_workgroups<2, 2, MODE, true, FAST, 32, true>());
     }
     else if (sx == 2 && sy == 2 && direct_420())
@@ -1298,6 +1441,15 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     // 4:2:2 likewise (the chroma blocks under a strip are one per work-item; see IN422)
     bool inthread = chroma && L.scale_y == 1;
     if (chroma && strip_chroma_420(L, n_images)) inthread = true;   // small single 4:2:0 images too (IN420)
+    const bool fast_out = (L.width & 15) == 0 && (pixel_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
+    const bool quad = chroma && quad_enabled() && L.scale_x == 2 && L.scale_y == 2 && fast_out &&
+                      L.units_x[0] % 32 == 0 && L.units_y[0] % 8 == 0 && strip_width(L.units_x[0], L.units_y[0], 2, 2) == 32 &&
+                      (L.width & 255) == 0 && (L.height & 63) == 0 &&
+                      // the stacks above and below (workgroup t -+ tiles_x) must run on the same XCD, whose L2 then serves the
+                      // halo rows' coefficient blocks a second time: workgroups are dealt to the XCDs modulo 8
+                      // (256 x 512 x 512 images: 96.0 us against 94.4 with the two launches; 16 x 2048 x 2048: 94.7 against 95.8)
+                      (L.units_x[0] / 32) % 8 == 0;
+    if (quad) inthread = true;
     const bool two_launches = chroma && !inthread;
     LumaArgs la{};
     ChromaArgs ca{};
@@ -1337,6 +1489,7 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     la.tiles_per_image = la.tiles_x * strips_y;
     la.first_tile = 0;
     la.total_tiles = la.tiles_per_image * n_images;
+    la.quad = quad ? 1 : 0;
     if (la.total_tiles == 0) return hipSuccess;
     const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;

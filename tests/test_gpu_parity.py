@@ -453,3 +453,4 @@ def test_cosited_through_the_fused_entry_point_parity_unpinned_no_reference_gold
         rect = O.interleave(want_p, fs, layout.scale, size, cosited=cosite)
         assert (spectral.decode(J.RGB, cosite=cosite).cpu().numpy() == O.unpack_rgb8(rect, 3)).all()
         assert (spectral.decode(J.YCbCr, cosite=cosite).cpu().numpy() == O.unpack_ycc8(rect, 3)).all()
+

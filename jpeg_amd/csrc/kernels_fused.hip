@@ -613,7 +613,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         // and all waves of a SIMD leave within a strip of each other (ends between 47 and 66 us).
         {
             const int rem = (len - 1 - k) / nwaves;   // strips after this one
-            if (rem >= 3) __builtin_amdgcn_s_setprio(3);
+            if constexpr (QUAD) __builtin_amdgcn_s_setprio(3);   // see the meeting point below
+            else if (rem >= 3) __builtin_amdgcn_s_setprio(3);
             else if (rem == 2) __builtin_amdgcn_s_setprio(2);
             else if (rem == 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
@@ -726,6 +727,15 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                 }
             }
             __syncthreads();   // the tile is complete (all four waves' samples)
+            // Up to here the wave ran at the top priority (whoever is late for the meeting point is waited for by three
+            // others); from here on at most at priority 2, by strips left like the other walks.  88.5 against 91.8 us at
+            // 8192 x 8192 (profiles/r02_ab_quad_priority.txt).
+            {
+                const int rem2 = (len - 1 - k) / nwaves;
+                if (rem2 >= 2) __builtin_amdgcn_s_setprio(2);
+                else if (rem2 == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             if (wave == 0 || wave == NW - 1) {
                 // image top / bottom: a missing row is the nearest own row (decode.swift:4246); then its two edge columns
                 const int hr = wave == 0 ? 0 : QROWS - 1, src = wave == 0 ? 1 : QROWS - 2;

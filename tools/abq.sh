@@ -1,7 +1,12 @@
-export JPEG_AMD_QUAD=1
+# alternating runs of builds of the library on QUAD-shaped images: tools/abq.sh name... (tools/exp/libjpeg_amd_<name>.so; "product" = the product build)
 for r in 1 2 3; do
-  for l in "" qb2end; do echo -n "lib=${l:-product} "; JPEG_AMD_LIBRARY=${l:+tools/exp/libjpeg_amd_$l.so} python tools/run_c3.py 300 2>/dev/null; done
-  echo -n "two-launch  "; JPEG_AMD_QUAD=0 python tools/run_c3.py 300 2>/dev/null
+  for l in "$@"; do
+    lib=""; [ "$l" != product ] && lib=tools/exp/libjpeg_amd_$l.so
+    echo -n "$l: "; JPEG_AMD_LIBRARY=$lib python tools/run_c3.py 300 2>/dev/null
+  done
 done
-for l in "" qb2end; do echo -n "lib=${l:-product} "; JPEG_AMD_LIBRARY=${l:+tools/exp/libjpeg_amd_$l.so} python tools/run_c3.py 300 4096 4096 1 2>/dev/null; done
-echo -n "strip420    "; JPEG_AMD_QUAD=0 python tools/run_c3.py 300 4096 4096 1 2>/dev/null
+for l in "$@"; do
+  lib=""; [ "$l" != product ] && lib=tools/exp/libjpeg_amd_$l.so
+  echo -n "$l: "; JPEG_AMD_LIBRARY=$lib python tools/run_c3.py 300 4096 4096 1 2>/dev/null
+  echo -n "$l: "; JPEG_AMD_LIBRARY=$lib python tools/run_c3.py 100 2048 2048 16 2>/dev/null
+done

@@ -719,12 +719,16 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             }
             // the plane's left / right edge: the reference clamps the sample index (decode.swift:4245) -- own rows here,
             // the two halo rows after the barrier (their samples come from other waves)
-            if (!has_left || !has_right) {
-                if (lane < 16) {
-                    uint32_t *row = qtile + (lane >> 3) * PLANE + (1 + 8 * wave + (lane & 7)) * PITCH;
-                    if (!has_left) row[0] = (row[1] & 0xffu) * 0x01010101u;
-                    if (!has_right) row[PITCH - 1] = (row[PITCH - 2] >> 24) * 0x01010101u;
+            const int first_bad = (a.pw_c >> 2) - (sxi * CW - HX) / 4;   // first tile dword past the plane (PITCH - 1 at a full last tile)
+            auto fix_columns = [&](uint32_t *row) {
+                if (!has_left) row[0] = (row[1] & 0xffu) * 0x01010101u;
+                if (first_bad < PITCH) {
+                    const uint32_t last = (row[first_bad - 1] >> 24) * 0x01010101u;
+                    for (int c = first_bad; c < PITCH; ++c) row[c] = last;
                 }
+            };
+            if (!has_left || first_bad < PITCH) {
+                if (lane < 16) fix_columns(qtile + (lane >> 3) * PLANE + (1 + 8 * wave + (lane & 7)) * PITCH);
             }
             __syncthreads();   // the tile is complete (all four waves' samples)
             // Up to here the wave ran at the top priority (whoever is late for the meeting point is waited for by three
@@ -745,10 +749,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                         uint32_t *col = qtile + (d >= PITCH ? PLANE + d - PITCH : d);
                         col[hr * PITCH] = col[src * PITCH];
                     }
-                } else if ((!has_left || !has_right) && lane < 2) {
-                    uint32_t *row = qtile + lane * PLANE + hr * PITCH;
-                    if (!has_left) row[0] = (row[1] & 0xffu) * 0x01010101u;
-                    if (!has_right) row[PITCH - 1] = (row[PITCH - 2] >> 24) * 0x01010101u;
+                } else if ((!has_left || first_bad < PITCH) && lane < 2) {
+                    fix_columns(qtile + lane * PLANE + hr * PITCH);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1257,11 +1259,15 @@ inline bool direct_420()
 
 // JPEG_AMD_QUAD=0: 4:2:0 images that are a whole number of 256 x 64-pixel stacks take the two launches (or STRIP420) like
 // every other image instead of k_luma_fused's QUAD walk (one launch, the four waves of a workgroup sharing a chroma tile)
-inline bool quad_enabled()
+// JPEG_AMD_QUAD=2 (development switch) also sends images with a partial last tile column / strip row through QUAD, e.g.
+// 1920 x 1080: bit-identical, but the half-empty eighth column of strips costs more than the walk gains (512 x 1080p:
+// 1 582 against 1 491 us with 16 x 4 strips and two launches, profiles/r02_ab_quad_any_width.txt)
+inline int quad_mode()   // 0: off, 1: default rule, 2: see above
 {
-    static const bool v = [] { const char *e = std::getenv("JPEG_AMD_QUAD"); return !(e && e[0] == '0'); }();
+    static const int v = [] { const char *e = std::getenv("JPEG_AMD_QUAD"); return e ? std::atoi(e) : 1; }();
     return v;
 }
+inline bool quad_enabled() { return quad_mode() != 0; }
 
 // development switch: JPEG_AMD_XCD_IMAGES=1 gives every image of a batch to one XCD (LumaArgs::xcd_images).  OFF by default:
 // it does what it was built for -- k_luma_fused's FETCH_SIZE for 512 x 1080p drops from 3.30 to 2.71 GB, the chroma planes
@@ -1452,13 +1458,14 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     bool inthread = chroma && L.scale_y == 1;
     if (chroma && strip_chroma_420(L, n_images)) inthread = true;   // small single 4:2:0 images too (IN420)
     const bool fast_out = (L.width & 15) == 0 && (pixel_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-    const bool quad = chroma && quad_enabled() && L.scale_x == 2 && L.scale_y == 2 && fast_out &&
+    const bool quad_any = quad_mode() == 2 && chroma && L.scale_x == 2 && L.scale_y == 2 && fast_out && ((L.units_y[0] + 1) / 2) % 4 == 0;
+    const bool quad = quad_any || (chroma && quad_enabled() && L.scale_x == 2 && L.scale_y == 2 && fast_out &&
                       L.units_x[0] % 32 == 0 && L.units_y[0] % 8 == 0 && strip_width(L.units_x[0], L.units_y[0], 2, 2) == 32 &&
                       (L.width & 255) == 0 && (L.height & 63) == 0 &&
                       // the stacks above and below (workgroup t -+ tiles_x) must run on the same XCD, whose L2 then serves the
                       // halo rows' coefficient blocks a second time: workgroups are dealt to the XCDs modulo 8
                       // (256 x 512 x 512 images: 96.0 us against 94.4 with the two launches; 16 x 2048 x 2048: 94.7 against 95.8)
-                      (L.units_x[0] / 32) % 8 == 0;
+                      (L.units_x[0] / 32) % 8 == 0);
     if (quad) inthread = true;
     const bool two_launches = chroma && !inthread;
     LumaArgs la{};
@@ -1493,7 +1500,7 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     la.out = d_pixels; la.out_stride = pixel_stride;
     // unit of work: strip of 32 x 2 (or 16 x 4) luma blocks; persistent waves, 3 per SIMD (VGPR- and LDS-bound)
     const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;
-    const int bx = strip_width(la.ux, la.uy, sx, sy), by = 64 / bx;
+    const int bx = quad ? 32 : strip_width(la.ux, la.uy, sx, sy), by = 64 / bx;
     la.tiles_x = (la.ux + bx - 1) / bx;
     const int strips_y = (la.uy + by - 1) / by;
     la.tiles_per_image = la.tiles_x * strips_y;

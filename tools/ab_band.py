@@ -49,7 +49,10 @@ def main():
     var = "JPEG_AMD_BAND"
     for a in sys.argv[1:]:
         if a.startswith("--env="): var = a[6:]
-    for mode in ("0", "1"):
+    modes = ("0", "1")
+    for a in sys.argv[1:]:
+        if a.startswith("--modes="): modes = tuple(a[8:].split(","))
+    for mode in modes:
         env = dict(os.environ)
         env[var] = mode
         p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + [a for a in sys.argv[1:]], env=env,
@@ -59,11 +62,11 @@ def main():
             sys.exit(1)
         res[mode] = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
     bad = 0
-    for a, b in zip(res["0"], res["1"]):
+    for a, b in zip(res[modes[0]], res[modes[1]]):
         same = a["rgb_sha"] == b["rgb_sha"] and a["ycc_sha"] == b["ycc_sha"]
         bad += not same
         W, H, N = a["case"]
-        print(f"{N:4d} x {W}x{H}: {var}=0 RGB {a['rgb_us']:8.1f} YCC {a['ycc_us']:8.1f} us | =1 RGB {b['rgb_us']:8.1f} YCC {b['ycc_us']:8.1f} us | "
+        print(f"{N:4d} x {W}x{H}: {var}={modes[0]} RGB {a['rgb_us']:8.1f} YCC {a['ycc_us']:8.1f} us | ={modes[1]} RGB {b['rgb_us']:8.1f} YCC {b['ycc_us']:8.1f} us | "
               f"{'identical' if same else 'DIFFERENT'}")
     sys.exit(1 if bad else 0)
 

@@ -1257,7 +1257,7 @@ inline bool direct_420()
     return v;
 }
 
-// JPEG_AMD_QUAD=0: 4:2:0 images that are a whole number of 256 x 64-pixel stacks take the two launches (or STRIP420) like
+// JPEG_AMD_QUAD=0: 4:2:0 images made of whole tile columns and whole stacks take the two launches (or STRIP420) like
 // every other image instead of k_luma_fused's QUAD walk (one launch, the four waves of a workgroup sharing a chroma tile)
 // JPEG_AMD_QUAD=2 (development switch) also sends images with a partial last tile column / strip row through QUAD, e.g.
 // 1920 x 1080: bit-identical, but the half-empty eighth column of strips costs more than the walk gains (512 x 1080p:
@@ -1267,7 +1267,6 @@ inline int quad_mode()   // 0: off, 1: default rule, 2: see above
     static const int v = [] { const char *e = std::getenv("JPEG_AMD_QUAD"); return e ? std::atoi(e) : 1; }();
     return v;
 }
-inline bool quad_enabled() { return quad_mode() != 0; }
 
 // development switch: JPEG_AMD_XCD_IMAGES=1 gives every image of a batch to one XCD (LumaArgs::xcd_images).  OFF by default:
 // it does what it was built for -- k_luma_fused's FETCH_SIZE for 512 x 1080p drops from 3.30 to 2.71 GB, the chroma planes
@@ -1458,14 +1457,12 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     bool inthread = chroma && L.scale_y == 1;
     if (chroma && strip_chroma_420(L, n_images)) inthread = true;   // small single 4:2:0 images too (IN420)
     const bool fast_out = (L.width & 15) == 0 && (pixel_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-    const bool quad_any = quad_mode() == 2 && chroma && L.scale_x == 2 && L.scale_y == 2 && fast_out && ((L.units_y[0] + 1) / 2) % 4 == 0;
-    const bool quad = quad_any || (chroma && quad_enabled() && L.scale_x == 2 && L.scale_y == 2 && fast_out &&
-                      L.units_x[0] % 32 == 0 && L.units_y[0] % 8 == 0 && strip_width(L.units_x[0], L.units_y[0], 2, 2) == 32 &&
-                      (L.width & 255) == 0 && (L.height & 63) == 0 &&
-                      // the stacks above and below (workgroup t -+ tiles_x) must run on the same XCD, whose L2 then serves the
-                      // halo rows' coefficient blocks a second time: workgroups are dealt to the XCDs modulo 8
-                      // (256 x 512 x 512 images: 96.0 us against 94.4 with the two launches; 16 x 2048 x 2048: 94.7 against 95.8)
-                      (L.units_x[0] / 32) % 8 == 0);
+    // QUAD: whole stacks of four strips (any height whose last strip row completes a stack) and whole 256-pixel tile columns.
+    // (With the priorities around the meeting point it also wins where the stacks above and below run on other XCDs:
+    // 256 x 512 x 512 93.5 against 100.5 us, 5120 x 5120 44.1 against 49.2, profiles/r02_ab_quad_shapes.txt.  A partial last
+    // column does not pay: JPEG_AMD_QUAD=2.)
+    const bool quad_base = chroma && L.scale_x == 2 && L.scale_y == 2 && fast_out && ((L.units_y[0] + 1) / 2) % 4 == 0;
+    const bool quad = quad_base && (quad_mode() == 2 || (quad_mode() == 1 && L.units_x[0] % 32 == 0 && (L.width & 255) == 0));
     if (quad) inthread = true;
     const bool two_launches = chroma && !inthread;
     LumaArgs la{};

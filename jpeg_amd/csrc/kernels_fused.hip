@@ -302,7 +302,12 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     // (56 work-items busy); after a barrier every wave finds its halo rows in its neighbours' samples.  2.0 IDCT passes
     // per strip where STRIP420 needs 2.7 (44 + 64 work-items, the second pass at two thirds of the arithmetic) and the
     // two launches 1.5 -- and no chroma samples through HBM.
-    constexpr bool QUAD = QUAD_ && STRIP420 && CHROMA && SX == 2 && SY == 2 && BX == 32;
+    // The same for 16 x 4 strips (128 x 32 pixels, what 1920 x 1080 is made of): a strip has two chroma block rows, so TWO
+    // stacked strips fill a wave's pass (32 own blocks, 16 of the 32 halo-row blocks, 8 side blocks, 4 corner blocks: 60
+    // work-items) and a workgroup walks two independent stacks that share nothing but the barrier.
+    constexpr bool QUAD = QUAD_ && STRIP420 && CHROMA && SX == 2 && SY == 2;
+    constexpr int QS = BX == 32 ? 4 : 2;                 // QUAD: strips (= waves) per stack
+    constexpr int QG = (kThreads / 64) / QS;             // QUAD: stacks per workgroup
     // ALIAS (two-launch 4:2:0): the chroma tile lives INSIDE the wave's coefficient buffer.  The buffer is only needed
     // from the prefetch of the next strip's coefficients to their read-back at the top of that strip, the tile from
     // there to the last chroma read of the pixel rows (row 5) -- so the prefetch is issued after row 5 instead of
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     // transforms the Cb and Cr blocks that lie under its luma block itself (same geometry), parks
     // their samples as bytes in LDS ([dword][lane], like k_encode_fused) and then does the luma block
     constexpr bool INTHREAD = CHROMA && SX == 1 && SY == 1;
-    constexpr int QROWS = 4 * CR + 2;                    // QUAD: sample rows of the shared tile (halo, 4 x 8 rows, halo)
+    constexpr int QROWS = QS * CR + 2;                   // QUAD: sample rows of a stack's tile (halo, QS x CR rows, halo): 34
     constexpr int PLANE = QUAD ? QROWS * PITCH : (CHROMA && !INTHREAD) ? ROWS * PITCH : 1;   // dwords per plane of the tile
     constexpr int SEG_DW = BX * 6;                       // one pixel row of one block row: 24 B per block
     constexpr int CPS = SEG_DW / 4;                      // 16-byte chunks per such segment
@@ -352,13 +357,13 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     // 27 instead of 31 us there, 12.4 instead of 14.5 at 2048 x 2048), it ties at 8192 x 8192 and loses on
     // batches of narrower images, whose vertical neighbours run on other XCDs and miss in L2 (+ 15 %).
     constexpr bool IN420 = STRIP420 && CHROMA && SX == 2 && SY == 2 && BX == 32;
-    constexpr bool INSTRIP = INTHREAD || IN422 || IN420;   // no k_chroma_idct in front of this kernel
+    constexpr bool INSTRIP = INTHREAD || IN422 || IN420 || QUAD;   // no k_chroma_idct in front of this kernel
     constexpr int NTAB = INSTRIP ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][DIRECT ? 4 : 64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     static_assert(!ALIAS || 2 * PLANE <= 64 * 32, "the chroma tile must fit the coefficient buffer");
     __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : (ALIAS || QUAD) ? 1 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
-    __shared__ uint32_t qtile[QUAD ? 2 * PLANE : 1];     // QUAD: the workgroup's tile; wave w's window starts at sample row 8 w
+    __shared__ uint32_t qtile[QUAD ? QG * 2 * PLANE : 1];   // QUAD: one tile per stack; the window of the wave at position p starts at sample row CR p
     __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
 
     const int lane0 = threadIdx.x & 63;
@@ -368,7 +373,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     // LDS byte address of the wave's coefficient buffer (low 32 bits of the flat shared address)
     const uint32_t coef_lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)coef_w);
-    uint32_t *sc = ALIAS ? coef_w : QUAD ? qtile + 8 * wave * PITCH : scw[wave];
+    const int qp = wave % QS, qg = wave / QS;            // QUAD: position in the stack, stack of the workgroup
+    uint32_t *qt = qtile + (QUAD ? qg * 2 * PLANE : 0);  // QUAD: this stack's tile
+    uint32_t *sc = ALIAS ? coef_w : QUAD ? qt + CR * qp * PITCH : scw[wave];
     const uint32_t sc_lds = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sc);
     float *sq = sqw[wave][0];
@@ -383,6 +390,26 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 
     // LDS-DMA of the 64 blocks of strip s: instruction i moves 64 x 16 B; slot
     // u = 64 i + lane holds chunk (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3.
+    // QUAD: what work-item b of the wave at position qp transforms in the stack's chroma pass (CBW x CBR chroma blocks per plane lie
+    // under a strip):
+    //   0..31            the strip's own blocks: plane b >> 4, then row-major (b & 15) over CBR rows of CBW columns
+    //   32..47           the block row above the stack (first half of the stack's waves) or below it (second half), column
+    //                    b & (CBW - 1); the plane is the wave's parity (four waves: 16 columns each) or bit 3 of b (two waves)
+    //   48..48+4 CBR-1   left / right neighbours of the own rows: row (b - 48) >> 2, plane bit 1, side bit 0
+    //   then 4           the same two columns of the row above (first wave) / below (last wave) the stack: corner samples
+    constexpr int CBW = BX / 2, CBR = BY / 2;
+    constexpr int QCORN0 = 48 + 4 * CBR, QEND = QCORN0 + 4;
+    auto quad_block = [&](int b, int syi, int sxi, int &pl, int &bx, int &by) {
+        const int top = syi - qp;                                         // strip row of the stack's first strip
+        const int above_row = CBR * top - 1, below_row = CBR * (top + QS);   // chroma block rows (clamped by the caller)
+        if (b < 32) { const int idx = b & 15; pl = b >> 4; bx = CBW * sxi + idx % CBW; by = CBR * syi + idx / CBW; }
+        else if (b < 48) { pl = BX == 32 ? (qp & 1) : ((b >> 3) & 1); bx = CBW * sxi + (b & (CBW - 1)); by = qp < QS / 2 ? above_row : below_row; }
+        else {
+            const int j = b < QCORN0 ? b - 48 : b - QCORN0;
+            pl = (j >> 1) & 1; bx = (j & 1) ? CBW * sxi + CBW : CBW * sxi - 1;
+            by = b < QCORN0 ? CBR * syi + (j >> 2) : (qp == 0 ? above_row : below_row);
+        }
+    };
     // which: 0 luma; 4:4:4: 1 Cb, 2 Cr; 4:2:2: 1 both chroma planes under the strip, 2 their halo blocks
     auto dma_strip = [&](int s, int lane, int which = 0) {
         int img, syi, sxi;
@@ -392,22 +419,14 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
         }
         if constexpr (QUAD) {
-            if (which == 3) {
-                // the wave's chroma pass.  Block b (= the work-item that transforms it):
-                //   0..31  plane b >> 4, column b & 15 of the wave's own chroma block row (= its strip row syi)
-                //   32..47 column b & 15 of the row above the stack (waves 0, 1: plane = wave) or below it (waves 2, 3: plane = wave - 2)
-                //   48..51 the own row's neighbours: plane (b >> 1) & 1, side b & 1 (0: column 16 sxi - 1, 1: column 16 sxi + 16)
-                //   52..55 the same two columns of the row above (wave 0) / below (wave 3) the stack: the tile's corner samples
+            if (which == 3) {   // the wave's chroma pass: block b is what work-item b transforms (quad_block)
                 const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
-                const int top = syi - wave;   // first strip row of the stack
-                const int halo_row = min(max(wave < 2 ? top - 1 : top + NW, 0), uyc - 1);   // missing rows: fetched, not used
 #pragma unroll
-                for (int i = 0; i < 7; ++i) {
+                for (int i = 0; i < (QEND + 7) / 8; ++i) {
                     const int b = 8 * i + (lane >> 3);
                     int pl, bx, by;
-                    if (i < 4) { pl = i >> 1; bx = 16 * sxi + (b & 15); by = syi; }
-                    else if (i < 6) { pl = wave & 1; bx = 16 * sxi + (b & 15); by = halo_row; }
-                    else { pl = (b >> 1) & 1; bx = (b & 1) ? 16 * sxi + 16 : 16 * sxi - 1; by = b < 52 ? syi : halo_row; }
+                    quad_block(b, syi, sxi, pl, bx, by);
+                    by = min(max(by, 0), uyc - 1);   // missing rows: fetched, not used
                     const int16_t *cbase = a.ccoef[pl] + img * a.ccoef_stride[pl];
                     const uint32_t blk = (bx >= 0 && bx < uxc) ? (uint32_t)by * uxc + bx : 0u;
                     const int c = (lane & 7) ^ ((b >> 1) & 7);
@@ -527,19 +546,23 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 
     // The wave's walk: elements k, k + stride, ... of a list of `len` strips.  One list for the launch (strip = first_tile + k),
     // or one list per residue of blockIdx.x mod 8 (xcd_images: the strips of images x, x + 8, ... back to back).
-    // QUAD: the WORKGROUP walks stacks of four strips (the host only selects it when every image is a whole number of
-    // stacks); wave w takes strip row 4 R + w of stack (R, column c).  All four waves make the same number of trips:
-    // the barriers inside the loop are met by everyone.
+    // QUAD: the WORKGROUP walks stacks of QS strips, QG of them per trip (the host only selects it when every image is a whole
+    // number of stacks); the wave at position qp of stack qg takes strip row QS R + qp of stack (R, column c).  All waves make
+    // the same number of trips -- the barriers inside the loop are met by everyone; a wave whose stack does not exist
+    // (odd number of stacks, last trip) only keeps the others company there.
     const bool by_xcd = !QUAD && a.xcd_images > 0;
     const int xcd = by_xcd ? (int)(blockIdx.x & 7u) : 0;
     const int nwaves = QUAD ? (int)gridDim.x : by_xcd ? (int)(gridDim.x >> 3) * NW : (int)gridDim.x * NW;   // the walk's stride
-    const int len = QUAD ? a.total_tiles / NW : by_xcd ? ((a.xcd_images - xcd + 7) >> 3) * a.tiles_per_image : a.total_tiles - a.first_tile;
+    const int nstacks = QUAD ? a.total_tiles / QS : 0;
+    const int len = QUAD ? (nstacks + QG - 1) / QG : by_xcd ? ((a.xcd_images - xcd + 7) >> 3) * a.tiles_per_image : a.total_tiles - a.first_tile;
+    auto valid = [&](int k) -> bool { return k < len && (!QUAD || k * QG + qg < nstacks); };
     auto strip_at = [&](int k) -> int {
         if constexpr (QUAD) {
-            const int per_image = a.tiles_per_image / NW;
-            const int im = k / per_image, rem = k - im * per_image;
+            const int q = min(k * QG + qg, nstacks - 1);
+            const int per_image = a.tiles_per_image / QS;
+            const int im = q / per_image, rem = q - im * per_image;
             const int R = rem / a.tiles_x, c = rem - R * a.tiles_x;
-            return im * a.tiles_per_image + (NW * R + wave) * a.tiles_x + c;
+            return im * a.tiles_per_image + (QS * R + qp) * a.tiles_x + c;
         }
         if (!by_xcd) return a.first_tile + k;
         const int q = k / a.tiles_per_image;
@@ -563,7 +586,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         }
     };
     if constexpr (DIRECT) fetch_block(s, lane0);
-    else dma_strip(s, lane0, QUAD ? 3 : INSTRIP ? 1 : 0);
+    else if (valid(k)) dma_strip(s, lane0, QUAD ? 3 : INSTRIP ? 1 : 0);
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
 #ifdef JA_PHASE_PROFILE
@@ -573,6 +596,13 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 #endif
 
     for (; k < len; k += nwaves, s = strip_at(min(k, len - 1))) {
+        if constexpr (QUAD) {
+            if (!valid(k)) {   // no stack for this wave in the last trip: keep the two appointments of the trip
+                __syncthreads();
+                __syncthreads();
+                continue;
+            }
+        }
         // Launder the lane id once per strip: everything below that depends only on the lane is
         // cheap to recompute, but hoisted out of this loop it would pin ~60 VGPRs for good.
         int lane = lane0;
@@ -666,9 +696,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 
         if constexpr (QUAD) {
             const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
-            const int top = syi - wave;
-            const bool stack_above = top > 0, stack_below = top + NW < uyc;   // workgroup-uniform
-            const bool has_left = sxi > 0, has_right = 16 * sxi + 16 < uxc;
+            const int top = syi - qp;
+            const bool stack_above = top > 0, stack_below = CBR * (top + QS) < uyc;   // uniform over the stack
+            const bool has_left = sxi > 0, has_right = CBW * sxi + CBW < uxc;
             auto pack4 = [](const float *v) -> uint32_t {
                 uint32_t d = 0;
 #pragma unroll
@@ -680,40 +710,41 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             dma_strip(s, lane, 0);
             {
-                const int pl = lane < 32 ? lane >> 4 : lane < 48 ? (wave & 1) : (lane >> 1) & 1;
+                int pl, bx_, by_;
+                quad_block(lane, syi, sxi, pl, bx_, by_);
                 float g[64];
                 idct_block(w, sqw[wave][1 + pl], 128.5f, g);
                 // everyone has read the previous stack's tile before anyone overwrites it -- met HERE, after the transform, so
                 // that a wave that finished its pixel rows early spends the wait on the next stack's transform instead
-#ifndef JA_X_QUAD_B2_END
 #pragma unroll
                 for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(g[i]));
                 __syncthreads();
-#endif
-                uint32_t *tile = qtile + pl * PLANE;       // row 0: halo above the stack; rows 1 + 8 w ...: wave w; row QROWS - 1: halo below
+                uint32_t *tile = qt + pl * PLANE;          // row 0: halo above the stack; rows 1 + CR p ...: the wave at position p; row QROWS - 1: halo below
                 if (lane < 32) {
-                    uint32_t *dst = tile + (1 + 8 * wave) * PITCH + 1 + 2 * (lane & 15);
+                    const int idx = lane & 15;
+                    uint32_t *dst = tile + (1 + CR * qp + 8 * (idx / CBW)) * PITCH + 1 + 2 * (idx % CBW);
 #pragma unroll
                     for (int y = 0; y < 8; ++y) {
                         dst[y * PITCH] = pack4(&g[8 * y]);
                         dst[y * PITCH + 1] = pack4(&g[8 * y + 4]);
                     }
                 } else if (lane < 48) {
-                    if (wave < 2 ? stack_above : stack_below) {
-                        uint32_t *dst = tile + (wave < 2 ? 0 : QROWS - 1) * PITCH + 1 + 2 * (lane & 15);
-                        const float *row = wave < 2 ? &g[56] : &g[0];   // last row of the block above / first row of the block below
+                    const bool above = qp < QS / 2;
+                    if (above ? stack_above : stack_below) {
+                        uint32_t *dst = tile + (above ? 0 : QROWS - 1) * PITCH + 1 + 2 * (lane & (CBW - 1));
+                        const float *row = above ? &g[56] : &g[0];   // last row of the block above / first row of the block below
                         dst[0] = pack4(row);
                         dst[1] = pack4(row + 4);
                     }
-                } else if (lane < 56) {
-                    const int side = lane & 1;
+                } else if (lane < QEND) {
+                    const int j = lane < QCORN0 ? lane - 48 : lane - QCORN0, side = j & 1;
                     if (side ? has_right : has_left) {
                         uint32_t *col = tile + (side ? PITCH - 1 : 0);
-                        if (lane < 52) {
+                        if (lane < QCORN0) {
 #pragma unroll
-                            for (int y = 0; y < 8; ++y) col[(1 + 8 * wave + y) * PITCH] = rep1(side ? g[8 * y] : g[8 * y + 7]);
-                        } else if (wave == 0 && stack_above) col[0] = rep1(side ? g[56] : g[63]);
-                        else if (wave == NW - 1 && stack_below) col[(QROWS - 1) * PITCH] = rep1(side ? g[0] : g[7]);
+                            for (int y = 0; y < 8; ++y) col[(1 + CR * qp + 8 * (j >> 2) + y) * PITCH] = rep1(side ? g[8 * y] : g[8 * y + 7]);
+                        } else if (qp == 0 && stack_above) col[0] = rep1(side ? g[56] : g[63]);
+                        else if (qp == QS - 1 && stack_below) col[(QROWS - 1) * PITCH] = rep1(side ? g[0] : g[7]);
                     }
                 }
             }
@@ -728,10 +759,10 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                 }
             };
             if (!has_left || first_bad < PITCH) {
-                if (lane < 16) fix_columns(qtile + (lane >> 3) * PLANE + (1 + 8 * wave + (lane & 7)) * PITCH);
+                if (lane < 2 * CR) fix_columns(qt + (lane / CR) * PLANE + (1 + CR * qp + lane % CR) * PITCH);
             }
-            __syncthreads();   // the tile is complete (all four waves' samples)
-            // Up to here the wave ran at the top priority (whoever is late for the meeting point is waited for by three
+            __syncthreads();   // the tile is complete (all of the stack's samples)
+            // Up to here the wave ran at the top priority (whoever is late for the meeting point is waited for by the
             // others); from here on at most at priority 2, by strips left like the other walks.  88.5 against 91.8 us at
             // 8192 x 8192 (profiles/r02_ab_quad_priority.txt).
             {
@@ -740,17 +771,17 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                 else if (rem2 == 1) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
-            if (wave == 0 || wave == NW - 1) {
+            if (qp == 0 || qp == QS - 1) {
                 // image top / bottom: a missing row is the nearest own row (decode.swift:4246); then its two edge columns
-                const int hr = wave == 0 ? 0 : QROWS - 1, src = wave == 0 ? 1 : QROWS - 2;
-                const bool missing = wave == 0 ? !stack_above : !stack_below;
+                const int hr = qp == 0 ? 0 : QROWS - 1, src = qp == 0 ? 1 : QROWS - 2;
+                const bool missing = qp == 0 ? !stack_above : !stack_below;
                 if (missing) {
                     for (int d = lane; d < 2 * PITCH; d += 64) {
-                        uint32_t *col = qtile + (d >= PITCH ? PLANE + d - PITCH : d);
+                        uint32_t *col = qt + (d >= PITCH ? PLANE + d - PITCH : d);
                         col[hr * PITCH] = col[src * PITCH];
                     }
                 } else if ((!has_left || first_bad < PITCH) && lane < 2) {
-                    fix_columns(qtile + lane * PLANE + hr * PITCH);
+                    fix_columns(qt + lane * PLANE + hr * PITCH);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -996,7 +1027,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
         if constexpr (!DIRECT && !ALIAS) {
-            if (k + nwaves < len) dma_strip(strip_at(k + nwaves), lane, QUAD ? 3 : INSTRIP ? 1 : 0);
+            if (valid(k + nwaves)) dma_strip(strip_at(k + nwaves), lane, QUAD ? 3 : INSTRIP ? 1 : 0);
         }
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
@@ -1181,7 +1212,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             //      dwords of the next patch row ----
             if (y > 0) store_row(y - 1);
             if constexpr (DIRECT) {
-                if (y == 4 && k + nwaves < len) fetch_block(strip_at(k + nwaves), lane);
+                if (y == 4 && valid(k + nwaves)) fetch_block(strip_at(k + nwaves), lane);
             }
             uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
             sw[0] = make_uint2(d[0], d[1]);
@@ -1198,7 +1229,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                     if constexpr (ALIAS) {
                         if (y == 5) {   // the tile has been read for the last time: the next strip's coefficients may land on it
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (k + nwaves < len) dma_strip(strip_at(k + nwaves), lane, 0);
+                            if (valid(k + nwaves)) dma_strip(strip_at(k + nwaves), lane, 0);
                         }
                     }
                 } else if (y < 7) {
@@ -1209,9 +1240,6 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         }
         __builtin_amdgcn_sched_barrier(0);
         store_row(7);
-#ifdef JA_X_QUAD_B2_END
-        if constexpr (QUAD) __syncthreads();
-#endif
         JA_PHASE(5)
     }
 #ifdef JA_PHASE_PROFILE
@@ -1262,7 +1290,7 @@ inline bool direct_420()
 // JPEG_AMD_QUAD=2 (development switch) also sends images with a partial last tile column / strip row through QUAD, e.g.
 // 1920 x 1080: bit-identical, but the half-empty eighth column of strips costs more than the walk gains (512 x 1080p:
 // 1 582 against 1 491 us with 16 x 4 strips and two launches, profiles/r02_ab_quad_any_width.txt)
-inline int quad_mode()   // 0: off, 1: default rule, 2: see above
+inline int quad_mode()   // 0: off, 1: default rule, 2: see above, 4 (development): the 16 x 4-strip variant where those strips are used
 {
     static const int v = [] { const char *e = std::getenv("JPEG_AMD_QUAD"); return e ? std::atoi(e) : 1; }();
     return v;
@@ -1301,9 +1329,9 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
 #define JA_K(SX_, SY_, CH_) go(k_luma_fused<SX_, SY_, MODE, CH_, FAST, BX>, resident_workgroups<SX_, SY_, MODE, CH_, FAST, BX>());
     if (!chroma) JA_K(1, 1, false)
     else if (sx == 2 && sy == 2 && a.ccoef[0] != nullptr) {   // chroma transformed in the strip walk (IN420 / QUAD)
-        if constexpr (BX == 32 && FAST) {
+        if constexpr (FAST) {
             if (a.quad) {
-                go(k_luma_fused<2, 2, MODE, true, FAST, 32, true, false, false, true>, resident_workgroups<2, 2, MODE, true, FAST, 32, true, false, false, true>());
+                go(k_luma_fused<2, 2, MODE, true, FAST, BX, true, false, false, true>, resident_workgroups<2, 2, MODE, true, FAST, BX, true, false, false, true>());
                 return hipGetLastError();
             }
         }
@@ -1457,12 +1485,23 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     bool inthread = chroma && L.scale_y == 1;
     if (chroma && strip_chroma_420(L, n_images)) inthread = true;   // small single 4:2:0 images too (IN420)
     const bool fast_out = (L.width & 15) == 0 && (pixel_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-    // QUAD: whole stacks of four strips (any height whose last strip row completes a stack) and whole 256-pixel tile columns.
+    // QUAD: images made of whole 256-pixel tile columns and whole stacks of four 32 x 2-block strips; the last strip row of an
+    // image may be partial.  (The kernel also has the walk for 16 x 4 strips -- stacks of two, two stacks per workgroup,
+    // 1920 x 1080 is 15 x 17 of them -- but it is 12 % SLOWER than the two launches there: 1 552 against 1 369-1 394 us for
+    // 512 x 1080p, JPEG_AMD_QUAD=4.)
     // (With the priorities around the meeting point it also wins where the stacks above and below run on other XCDs:
     // 256 x 512 x 512 93.5 against 100.5 us, 5120 x 5120 44.1 against 49.2, profiles/r02_ab_quad_shapes.txt.  A partial last
     // column does not pay: JPEG_AMD_QUAD=2.)
-    const bool quad_base = chroma && L.scale_x == 2 && L.scale_y == 2 && fast_out && ((L.units_y[0] + 1) / 2) % 4 == 0;
-    const bool quad = quad_base && (quad_mode() == 2 || (quad_mode() == 1 && L.units_x[0] % 32 == 0 && (L.width & 255) == 0));
+    bool quad = false;
+    int quad_bx = 32;
+    if (chroma && L.scale_x == 2 && L.scale_y == 2 && fast_out && quad_mode() != 0) {
+        const int sw = strip_width(L.units_x[0], L.units_y[0], 2, 2);
+        const bool whole32 = ((L.units_y[0] + 1) / 2) % 4 == 0 && L.units_x[0] % 32 == 0 && (L.width & 255) == 0;
+        const bool whole16 = ((L.units_y[0] + 3) / 4) % 2 == 0 && L.units_x[0] % 16 == 0 && (L.width & 127) == 0;
+        if (quad_mode() == 2 && ((L.units_y[0] + 1) / 2) % 4 == 0) { quad = true; quad_bx = 32; }
+        else if (quad_mode() == 4 && sw == 16 && whole16) { quad = true; quad_bx = 16; }
+        else if (whole32) { quad = true; quad_bx = 32; }
+    }
     if (quad) inthread = true;
     const bool two_launches = chroma && !inthread;
     LumaArgs la{};
@@ -1497,7 +1536,7 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     la.out = d_pixels; la.out_stride = pixel_stride;
     // unit of work: strip of 32 x 2 (or 16 x 4) luma blocks; persistent waves, 3 per SIMD (VGPR- and LDS-bound)
     const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;
-    const int bx = quad ? 32 : strip_width(la.ux, la.uy, sx, sy), by = 64 / bx;
+    const int bx = quad ? quad_bx : strip_width(la.ux, la.uy, sx, sy), by = 64 / bx;
     la.tiles_x = (la.ux + bx - 1) / bx;
     const int strips_y = (la.uy + by - 1) / by;
     la.tiles_per_image = la.tiles_x * strips_y;

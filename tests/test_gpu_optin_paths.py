@@ -21,7 +21,7 @@ ctx = J.Context(0)
 rng = np.random.default_rng(11)
 quanta = [rng.integers(1, 30, 64).astype(np.uint16) for _ in range(2)]
 import os
-sizes = [(2048, 1540), (1000, 700), (520, 24), (17, 17), (4112, 520), (2048, 1024), (1920, 1080), (2064, 192)]   # QUAD-shaped: the third last; with JPEG_AMD_QUAD=2 the last two as well
+sizes = [(2048, 1540), (1000, 700), (520, 24), (17, 17), (4112, 520), (2048, 1024), (1920, 1080), (2064, 192), (640, 320), (128, 64)]   # QUAD-shaped: (2048, 1024); with JPEG_AMD_QUAD=2 also (1920, 1080) and (2064, 192); with =4 (1920, 1080), (640, 320), (128, 64) as stacks of two 16 x 4 strips
 if os.environ.get("JA_TEST_BIG"):   # enough strips / blocks for the part pipeline and the persistent chroma kernel to engage
     sizes = [(8192, 6416), (1000, 700)]
 for size in sizes:
@@ -42,7 +42,7 @@ print("ok")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("switch", ["JPEG_AMD_BAND=1", "JPEG_AMD_DIRECT=1", "JPEG_AMD_OVERLAP=1", "JPEG_AMD_K1_PERSIST=1",
-                                    "JPEG_AMD_ALIAS=1", "JPEG_AMD_QUAD=0", "JPEG_AMD_QUAD=2", "JPEG_AMD_ENC_TY=16"])
+                                    "JPEG_AMD_ALIAS=1", "JPEG_AMD_QUAD=0", "JPEG_AMD_QUAD=2", "JPEG_AMD_QUAD=4", "JPEG_AMD_ENC_TY=16"])
 def test_opt_in_path_matches_oracle(switch):
     k, v = switch.split("=")
     env = dict(os.environ)

@@ -184,6 +184,21 @@ __global__ __launch_bounds__(kThreads, 3) void k_chroma_idct_persist(ChromaPersi
 // ---------------------------------------------------------------------------------------
 // K2: luma IDCT + chroma upsample + colour + store
 // ---------------------------------------------------------------------------------------
+// Division by a launch-invariant: q = mulhi(n, floor((2^32 - 1) / d)) is the quotient or one below it for every n < 2^32, one
+// compare fixes it.  The strip walks divide a dozen times per trip (strip -> image, row, column; strips left); as true
+// divisions that is ~400 mostly scalar, serial instructions at the head of every trip.
+struct FastDiv {
+    uint32_t d, m;
+    __device__ __forceinline__ void set(uint32_t div) { d = div; m = 0xffffffffu / div; }
+    __device__ __forceinline__ uint32_t div(uint32_t n, uint32_t &r) const
+    {
+        uint32_t q = __umulhi(n, m);
+        r = n - q * d;
+        if (r >= d) { ++q; r -= d; }
+        return q;
+    }
+};
+
 struct LumaArgs {
     const int16_t *coef;
     size_t coef_stride;
@@ -381,11 +396,13 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     float *sq = sqw[wave][0];
 
     // strip s -> image, strip row (BY block rows), strip column (BX blocks)
+    FastDiv fd_tpi, fd_tx, fd_qpi;   // by strips per image, strips per row, stacks per image (QUAD)
+    fd_tpi.set((uint32_t)a.tiles_per_image); fd_tx.set((uint32_t)a.tiles_x); fd_qpi.set((uint32_t)max(a.tiles_per_image / QS, 1));
     auto locate = [&](int s, int &img, int &syi, int &sxi) {
-        img = s / a.tiles_per_image;
-        const int rem = s - img * a.tiles_per_image;
-        syi = rem / a.tiles_x;
-        sxi = rem - syi * a.tiles_x;
+        uint32_t rem, col;
+        img = (int)fd_tpi.div((uint32_t)s, rem);
+        syi = (int)fd_tx.div(rem, col);
+        sxi = (int)col;
     };
 
     // LDS-DMA of the 64 blocks of strip s: instruction i moves 64 x 16 B; slot
@@ -562,20 +579,22 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     const bool by_xcd = !QUAD && a.xcd_images > 0;
     const int xcd = by_xcd ? (int)(blockIdx.x & 7u) : 0;
     const int nwaves = QUAD ? (int)gridDim.x : by_xcd ? (int)(gridDim.x >> 3) * NW : (int)gridDim.x * NW;   // the walk's stride
+    FastDiv fd_nw; fd_nw.set((uint32_t)nwaves);
     const int nstacks = QUAD ? a.total_tiles / QS : 0;
     const int len = QUAD ? (nstacks + QG - 1) / QG : by_xcd ? ((a.xcd_images - xcd + 7) >> 3) * a.tiles_per_image : a.total_tiles - a.first_tile;
     auto valid = [&](int k) -> bool { return k < len && (!QUAD || k * QG + qg < nstacks); };
     auto strip_at = [&](int k) -> int {
         if constexpr (QUAD) {
             const int q = min(k * QG + qg, nstacks - 1);
-            const int per_image = a.tiles_per_image / QS;
-            const int im = q / per_image, rem = q - im * per_image;
-            const int R = rem / a.tiles_x, c = rem - R * a.tiles_x;
-            return im * a.tiles_per_image + (QS * R + qp) * a.tiles_x + c;
+            uint32_t rem, c;
+            const int im = (int)fd_qpi.div((uint32_t)q, rem);
+            const int R = (int)fd_tx.div(rem, c);
+            return im * a.tiles_per_image + (QS * R + qp) * a.tiles_x + (int)c;
         }
         if (!by_xcd) return a.first_tile + k;
-        const int q = k / a.tiles_per_image;
-        return (xcd + 8 * q) * a.tiles_per_image + (k - q * a.tiles_per_image);
+        uint32_t rem;
+        const int q = (int)fd_tpi.div((uint32_t)k, rem);
+        return (xcd + 8 * q) * a.tiles_per_image + (int)rem;
     };
     int k = QUAD ? (int)blockIdx.x : by_xcd ? (int)(blockIdx.x >> 3) * NW + wave : (int)blockIdx.x * NW + wave;
     if (k >= len) return;
@@ -651,7 +670,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         // few to keep it busy.  A wave with more strips left therefore runs at a higher priority: the laggards catch up
         // and all waves of a SIMD leave within a strip of each other (ends between 47 and 66 us).
         {
-            const int rem = (len - 1 - k) / nwaves;   // strips after this one
+            uint32_t rr_;
+            const int rem = (int)fd_nw.div((uint32_t)(len - 1 - k), rr_);   // strips after this one
             if constexpr (QUAD) __builtin_amdgcn_s_setprio(3);   // see the meeting point below
             else if (rem >= 3) __builtin_amdgcn_s_setprio(3);
             else if (rem == 2) __builtin_amdgcn_s_setprio(2);
@@ -775,7 +795,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             // others); from here on at most at priority 2, by strips left like the other walks.  88.5 against 91.8 us at
             // 8192 x 8192 (profiles/r02_ab_quad_priority.txt).
             {
-                const int rem2 = (len - 1 - k) / nwaves;
+                uint32_t rr_;
+                const int rem2 = (int)fd_nw.div((uint32_t)(len - 1 - k), rr_);
                 if (rem2 >= 2) __builtin_amdgcn_s_setprio(2);
                 else if (rem2 == 1) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);

@@ -289,9 +289,31 @@ __device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
 }
 
+// Split arrive / wait on an LDS counter (QUAD).  The LDS executes one wave's operations in issue order, so a ds_add issued
+// behind the wave's tile writes (or its last tile reads) is performed behind them: no s_waitcnt at the arrive.  The waiting
+// side polls with plain LDS reads; what it reads from the tile after the poll has succeeded is issued, and therefore
+// performed, after the read that saw the counter.  Relaxed atomics + compiler barriers on purpose: a release / acquire at
+// workgroup scope would make hipcc wait with vmcnt(0) -- for the coefficient DMA in flight and for the pixel stores.
+__device__ __forceinline__ void lds_arrive(uint32_t *counter, int lane)
+{
+    asm volatile("" ::: "memory");
+    if (lane == 0) (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_wait_ge(uint32_t *counter, uint32_t target)
+{
+#ifdef JA_X_NOSYNC   // experiment (wrong pixels): what do the waits of the QUAD walk cost?
+    return;
+#endif
+    asm volatile("" ::: "memory");
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+        __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
 #ifdef JA_PHASE_PROFILE
 // development aid (tools/phase_profile.py): wall cycles each wave spends per phase of a strip
-__device__ unsigned long long g_phase_cycles[4096 * 8];
+__device__ unsigned long long g_phase_cycles[4096 * 16];
 __device__ unsigned long long g_wave_info[4096 * 4];   // start tick, end tick (100 MHz counter), HW_ID, XCC_ID
 #define JA_PHASE(i)                                                       \
     {                                                                     \
@@ -380,6 +402,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : (ALIAS || QUAD) ? 1 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
     __shared__ uint32_t qtile[QUAD ? QG * 2 * PLANE : 1];   // QUAD: one tile per stack; the window of the wave at position p starts at sample row CR p
     __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
+    // QUAD: per stack, two monotonic counters instead of workgroup barriers.  [0] "ready": a wave has written its samples of
+    // this trip into the stack's tile; [1] "done": a wave has read the last sample of this trip that another wave wrote.
+    __shared__ uint32_t qsync[QUAD ? 2 * QG : 1];
 
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // strip math stays scalar
@@ -597,6 +622,10 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         return (xcd + 8 * q) * a.tiles_per_image + (int)rem;
     };
     int k = QUAD ? (int)blockIdx.x : by_xcd ? (int)(blockIdx.x >> 3) * NW + wave : (int)blockIdx.x * NW + wave;
+    if constexpr (QUAD) {
+        if (threadIdx.x < 2 * QG) qsync[threadIdx.x] = 0;
+        __syncthreads();   // the only workgroup barrier of the walk
+    }
     if (k >= len) return;
     int s = strip_at(k);
     // DIRECT: the block of the NEXT strip this work-item transforms, requested while the current one is worked on
@@ -618,18 +647,15 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
 #ifdef JA_PHASE_PROFILE
-    unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long phase_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = __builtin_readcyclecounter();
     const unsigned long long t_first = t_prev, r_first = __builtin_amdgcn_s_memrealtime();   // shader cycles / 100 MHz ticks
 #endif
 
+    uint32_t trip = 0;   // QUAD: trips this stack has completed (what its counters are compared with)
     for (; k < len; k += nwaves, s = strip_at(min(k, len - 1))) {
         if constexpr (QUAD) {
-            if (!valid(k)) {   // no stack for this wave in the last trip: keep the two appointments of the trip
-                __syncthreads();
-                __syncthreads();
-                continue;
-            }
+            if (!valid(k)) continue;   // no stack for this wave's pair in the last trip (the counters are per stack)
         }
         // Launder the lane id once per strip: everything below that depends only on the lane is
         // cheap to recompute, but hoisted out of this loop it would pin ~60 VGPRs for good.
@@ -738,16 +764,24 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             // w holds the chroma pass's block (read at the top); the luma blocks of the strip follow it into the buffer
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             dma_strip(s, lane, 0);
+            JA_PHASE(1)
             {
                 int pl, bx_, by_;
                 quad_block(lane, syi, sxi, pl, bx_, by_);
                 float g[64];
+#ifdef JA_X_NOCIDCT   // experiment (wrong pixels): the QUAD walk without the arithmetic of its chroma transform
+#pragma unroll
+                for (int i = 0; i < 64; ++i) g[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff) + sqw[wave][1 + pl][i];
+#else
                 idct_block(w, sqw[wave][1 + pl], 128.5f, g);
-                // everyone has read the previous stack's tile before anyone overwrites it -- met HERE, after the transform, so
-                // that a wave that finished its pixel rows early spends the wait on the next stack's transform instead
+#endif
+                // everyone has read the previous trip's tile before anyone overwrites it -- checked HERE, after the transform:
+                // the others signalled "done" at the end of their previous strip, a transform ago, so this rarely waits
 #pragma unroll
                 for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(g[i]));
-                __syncthreads();
+                JA_PHASE(2)
+                lds_wait_ge(&qsync[2 * qg + 1], QS * trip);
+                JA_PHASE(3)
                 uint32_t *tile = qt + pl * PLANE;          // row 0: halo above the stack; rows 1 + CR p ...: the wave at position p; row QROWS - 1: halo below
                 if (lane < 32) {
                     const int idx = lane & 15;
@@ -790,10 +824,11 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
             if (!has_left || first_bad < PITCH) {
                 if (lane < 2 * CR) fix_columns(qt + (lane / CR) * PLANE + (1 + CR * qp + lane % CR) * PITCH);
             }
-            __syncthreads();   // the tile is complete (all of the stack's samples)
-            // Up to here the wave ran at the top priority (whoever is late for the meeting point is waited for by the
-            // others); from here on at most at priority 2, by strips left like the other walks.  88.5 against 91.8 us at
-            // 8192 x 8192 (profiles/r02_ab_quad_priority.txt).
+            // this wave's samples are in the tile: arrive, do not wait -- the luma transform and six of the eight pixel rows need
+            // only the wave's own chroma rows.  Up to here the wave ran at the top priority (whoever arrives late is waited
+            // for by up to three others); from here on at most at priority 2, by strips left like the other walks.
+            lds_arrive(&qsync[2 * qg], lane);
+            JA_PHASE(4)
             {
                 uint32_t rr_;
                 const int rem2 = (int)fd_nw.div((uint32_t)(len - 1 - k), rr_);
@@ -801,23 +836,39 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                 else if (rem2 == 1) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
-            if (qp == 0 || qp == QS - 1) {
-                // image top / bottom: a missing row is the nearest own row (decode.swift:4246); then its two edge columns
-                const int hr = qp == 0 ? 0 : QROWS - 1, src = qp == 0 ? 1 : QROWS - 2;
-                const bool missing = qp == 0 ? !stack_above : !stack_below;
-                if (missing) {
-                    for (int d = lane; d < 2 * PITCH; d += 64) {
-                        uint32_t *col = qt + (d >= PITCH ? PLANE + d - PITCH : d);
-                        col[hr * PITCH] = col[src * PITCH];
-                    }
-                } else if ((!has_left || first_bad < PITCH) && lane < 2) {
-                    fix_columns(qt + lane * PLANE + hr * PITCH);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             read_block();
         }
+        // QUAD, after the wait for the stack's tile: the halo rows of the first / last wave.  Image top / bottom: a missing row is
+        // the nearest own row (decode.swift:4246); otherwise the row's two edge columns (decode.swift:4245) -- its samples came
+        // from other waves.  Only this wave reads the row it repairs.
+        auto quad_fix_halo_rows = [&]() {
+            if constexpr (QUAD) {
+                if (qp == 0 || qp == QS - 1) {
+                    const int uyc = a.ph_c >> 3, top = syi - qp;
+                    const bool stack_above = top > 0, stack_below = CBR * (top + QS) < uyc, has_left = sxi > 0;
+                    const int first_bad = (a.pw_c >> 2) - (sxi * CW - HX) / 4;
+                    auto one = [&](int hr, int src, bool missing) {
+                        if (missing) {
+                            for (int d = lane; d < 2 * PITCH; d += 64) {
+                                uint32_t *col = qt + (d >= PITCH ? PLANE + d - PITCH : d);
+                                col[hr * PITCH] = col[src * PITCH];
+                            }
+                        } else if ((!has_left || first_bad < PITCH) && lane < 2) {
+                            uint32_t *row = qt + lane * PLANE + hr * PITCH;
+                            if (!has_left) row[0] = (row[1] & 0xffu) * 0x01010101u;
+                            if (first_bad < PITCH) {
+                                const uint32_t last = (row[first_bad - 1] >> 24) * 0x01010101u;
+                                for (int c = first_bad; c < PITCH; ++c) row[c] = last;
+                            }
+                        }
+                    };
+                    if (qp == 0) one(0, 1, !stack_above);
+                    if (qp == QS - 1) one(QROWS - 1, QROWS - 2, !stack_below);
+                }
+            }
+        };
         if constexpr (IN420 && !QUAD) {
             const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
             const bool has_above = syi > 0, has_below = syi + 1 < uyc;        // wave-uniform
@@ -1018,7 +1069,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 
         // ---- luma: dequantise + IDCT, clamp + truncate (decode.swift:4121-4122), kept as
         //      integer-valued floats for the colour matrix ----
-        JA_PHASE(1)
+        JA_PHASE(5)
         float yv[64];
 #ifdef JA_X_NOIDCT  // experiment: how long is a strip without the IDCT arithmetic?
 #pragma unroll
@@ -1035,7 +1086,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 #pragma unroll
         for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(yv[i]));
         __builtin_amdgcn_sched_barrier(0);
-        JA_PHASE(2)
+        JA_PHASE(6)
 
         // ---- the chroma rows have landed (they are the only VM operations in flight) ----
         if constexpr (CHROMA && !INSTRIP) {
@@ -1061,7 +1112,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         }
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
-        JA_PHASE(3)
+        JA_PHASE(7)
 
         // ---- chroma rows, produced just in time from the LDS tile ----
         constexpr float inv = 1.0f / (float)((SX == 2 ? 4 : 1) * (SY == 2 ? 4 : 1));
@@ -1103,7 +1154,11 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
 
         float hw[2][3][8];  // SY == 2: patch rows j-1, j, j+1 of both planes (sliding window)
         uint32_t rawn[2][3] = {{0, 0, 0}, {0, 0, 0}};   // LDS dwords of the patch row that is converted next
-        if constexpr (CHROMA && SY == 2) {
+        if constexpr (QUAD) {
+            // pixel rows 1 ... 6 first (own chroma rows only): slot 0 = patch row 1 (kept for pixel row 0), slot 1 = patch row 2
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) { hrow(pl, 1, hw[pl][0]); hrow(pl, 2, hw[pl][1]); hraw(pl, 3, rawn[pl]); }
+        } else if constexpr (CHROMA && SY == 2) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) { hrow(pl, 0, hw[pl][0]); hrow(pl, 1, hw[pl][1]); hraw(pl, 2, rawn[pl]); }
         } else if constexpr (CHROMA) {
@@ -1127,7 +1182,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
         stores_behind_dma = (FAST && full) ? (ALIAS ? 6 : 16) : 0;
-        JA_PHASE(4)
+        JA_PHASE(8)
 
         // One pixel row of the strip's BY block rows at a time.  The row's LDS and memory traffic is software-
         // pipelined behind the NEXT row's arithmetic: row y is staged (ds_write) and read back as 16-byte chunks
@@ -1158,49 +1213,12 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                 if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);
             }
         };
+        // colour of pixel row y of the work-item's block from its luma samples and the row's chroma values; packed as 24 bytes
+        auto colour_row = [&](int y, const float (&cv)[2][8], uint32_t (&d)[6]) {
 #pragma unroll
-        for (int y = 0; y < 8; ++y) {  // pixel row y of every block row of the strip
-            __builtin_amdgcn_sched_barrier(0);
-            float cv[2][8];
-#ifdef JA_X_NOCOLOR   // experiment: the strip without the upsampling and colour arithmetic (memory operations and LDS traffic kept)
-            uint32_t dnc[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) dnc[j] = __float_as_uint(yv[8 * y + j]) ^ rawn[j & 1][j % 3];
-            if constexpr (false) {
-#else
-            if constexpr (CHROMA) {
-#endif
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    if constexpr (SY == 2) {
-                        // window holds patch rows (y>>1), (y>>1)+1, (y>>1)+2; the nearer row
-                        // (middle) weighs 3, the farther one (above for even y, below for odd) 1
-                        if ((y & 1) == 1) hconv(rawn[pl], hw[pl][2]);
-#pragma unroll
-                        for (int x = 0; x < 8; ++x)
-                            cv[pl][x] = finish(w31(hw[pl][1][x], hw[pl][(y & 1) ? 2 : 0][x]));
-                        if ((y & 1) == 1) {
-#pragma unroll
-                            for (int x = 0; x < 8; ++x) { hw[pl][0][x] = hw[pl][1][x]; hw[pl][1][x] = hw[pl][2][x]; }
-                        }
-                    } else {
-                        float h[8];
-                        hconv(rawn[pl], h);
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) cv[pl][x] = finish(h[x]);
-                    }
-                }
-            }
-            uint32_t d[6] = {0, 0, 0, 0, 0, 0};
-#ifdef JA_X_NOCOLOR
-#pragma unroll
-            for (int j = 0; j < 6; ++j) d[j] = dnc[j];
-#pragma unroll
-            for (int x = 0; x < 0; ++x) {
-#else
+            for (int j = 0; j < 6; ++j) d[j] = 0;
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
-#endif
                 const float yy = yv[8 * y + x];
                 float c0, c1, c2;
                 if constexpr (MODE == 1) {
@@ -1236,20 +1254,103 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
                 d[(3 * x + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c1, (3 * x + 1) & 3, d[(3 * x + 1) >> 2]);
                 d[(3 * x + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c2, (3 * x + 2) & 3, d[(3 * x + 2) >> 2]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- the row's traffic: store the PREVIOUS row's chunks (their LDS read was issued a row ago), stage
-            //      this row (LDS ops of one wave execute in order) and read it back as chunks, request the chroma
-            //      dwords of the next patch row ----
-            if (y > 0) store_row(y - 1);
-            if constexpr (DIRECT) {
-                if (y == 4 && valid(k + nwaves)) fetch_block(strip_at(k + nwaves), lane);
-            }
+        };
+        // the row's traffic: store the PREVIOUS row's chunks (their LDS read was issued a row ago; prev < 0: there is none),
+        // stage this row (LDS ops of one wave execute in order) and read it back as chunks
+        auto emit_row = [&](int prev, const uint32_t (&d)[6]) {
+            if (prev >= 0) store_row(prev);
             uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
             sw[0] = make_uint2(d[0], d[1]);
             sw[1] = make_uint2(d[2], d[3]);
             sw[2] = make_uint2(d[4], d[5]);
             pv0 = *reinterpret_cast<const uint4 *>(stage_w + 4 * lane);
             pv1 = *reinterpret_cast<const uint4 *>(stage_w + 4 * (64 + (lane & 31)));
+        };
+        if constexpr (QUAD) {
+            // Pixel rows in the order 1 2 3 4 5 6 | 0 7: only row 0 of the strip's first block row reads the sample row above
+            // the wave's own (patch row 0) and only row 7 of its second block row the one below (patch row 5) -- samples that
+            // OTHER waves of the stack produce.  The wave arrived at the "ready" counter before its luma transform and
+            // checks it only here, a transform and six pixel rows later.  Slots: hw[.][0] patch row 1 throughout,
+            // hw[.][1] / hw[.][2] the sliding pair.
+            auto step = [&](int y, int near, int far, int prev) {
+                __builtin_amdgcn_sched_barrier(0);
+                float cv[2][8];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) cv[pl][x] = finish(w31(hw[pl][near][x], hw[pl][far][x]));
+                uint32_t d[6];
+                colour_row(y, cv, d);
+                __builtin_amdgcn_sched_barrier(0);
+                emit_row(prev, d);
+            };
+            step(1, 0, 1, -1);                                    // patch rows 1 (near), 2
+            step(2, 1, 0, 1);                                     // 2, 1
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][2]);   // patch row 3
+            step(3, 1, 2, 2);                                     // 2, 3
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) hraw(pl, 4, rawn[pl]);
+            step(4, 2, 1, 3);                                     // 3, 2
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][1]);   // patch row 4 (row 2 is dead)
+            step(5, 2, 1, 4);                                     // 3, 4
+            step(6, 1, 2, 5);                                     // 4, 3
+            // ---- the stack's tile is complete: everyone's samples of this trip are in it ----
+            JA_PHASE(9)
+            lds_wait_ge(&qsync[2 * qg], QS * (trip + 1));
+            JA_PHASE(10)
+            quad_fix_halo_rows();
+            uint32_t raw0[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) { hraw(pl, 0, raw0[pl]); hraw(pl, 5, rawn[pl]); }
+            // those were this trip's last reads of samples another wave wrote (the LDS performs them before the add)
+            lds_arrive(&qsync[2 * qg + 1], lane);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) hconv(raw0[pl], hw[pl][2]);   // patch row 0 (row 3 is dead)
+            step(0, 0, 2, 6);                                     // 1, 0
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][2]);   // patch row 5
+            step(7, 1, 2, 0);                                     // 4, 5
+            __builtin_amdgcn_sched_barrier(0);
+            store_row(7);
+            ++trip;
+        } else {
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {  // pixel row y of every block row of the strip
+            __builtin_amdgcn_sched_barrier(0);
+            float cv[2][8];
+            if constexpr (CHROMA) {
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    if constexpr (SY == 2) {
+                        // window holds patch rows (y>>1), (y>>1)+1, (y>>1)+2; the nearer row
+                        // (middle) weighs 3, the farther one (above for even y, below for odd) 1
+                        if ((y & 1) == 1) hconv(rawn[pl], hw[pl][2]);
+#pragma unroll
+                        for (int x = 0; x < 8; ++x)
+                            cv[pl][x] = finish(w31(hw[pl][1][x], hw[pl][(y & 1) ? 2 : 0][x]));
+                        if ((y & 1) == 1) {
+#pragma unroll
+                            for (int x = 0; x < 8; ++x) { hw[pl][0][x] = hw[pl][1][x]; hw[pl][1][x] = hw[pl][2][x]; }
+                        }
+                    } else {
+                        float h[8];
+                        hconv(rawn[pl], h);
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) cv[pl][x] = finish(h[x]);
+                    }
+                }
+            }
+            uint32_t d[6];
+            colour_row(y, cv, d);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the row's traffic: the previous row's stores, this row's staging, and the request for the chroma
+            //      dwords of the next patch row ----
+            emit_row(y - 1, d);
+            if constexpr (DIRECT) {
+                if (y == 4 && valid(k + nwaves)) fetch_block(strip_at(k + nwaves), lane);
+            }
             if constexpr (CHROMA) {
                 if constexpr (SY == 2) {
                     if ((y & 1) == 1 && y < 7) {
@@ -1270,17 +1371,18 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA, DIRE
         }
         __builtin_amdgcn_sched_barrier(0);
         store_row(7);
-        JA_PHASE(5)
+        }
+        JA_PHASE(11)
     }
 #ifdef JA_PHASE_PROFILE
     // slots 6, 7: the wave's life in shader cycles and in ticks of the constant 100 MHz counter -> effective shader clock
-    phase_acc[6] = __builtin_readcyclecounter() - t_first;
-    phase_acc[7] = __builtin_amdgcn_s_memrealtime() - r_first;
+    phase_acc[14] = __builtin_readcyclecounter() - t_first;
+    phase_acc[15] = __builtin_amdgcn_s_memrealtime() - r_first;
     if (lane0 == 0 && blockIdx.x * NW + wave < 4096)
     {
-        for (int i = 0; i < 8; ++i) g_phase_cycles[(blockIdx.x * NW + wave) * 8 + i] = phase_acc[i];
+        for (int i = 0; i < 16; ++i) g_phase_cycles[(blockIdx.x * NW + wave) * 16 + i] = phase_acc[i];
         unsigned long long *wi = g_wave_info + (blockIdx.x * NW + wave) * 4;
-        wi[0] = r_first; wi[1] = r_first + phase_acc[7];
+        wi[0] = r_first; wi[1] = r_first + phase_acc[15];
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1352,6 +1454,9 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
     // grid = min(work, resident capacity); the per-XCD image partition needs the full, 8-divisible grid
     auto go = [&](auto kernel, int cap) {
         LumaArgs b = a;
+#ifdef JA_PHASE_PROFILE   // development aid: JA_GRID_CAP=256 runs one workgroup per CU (a wave alone on its SIMD)
+        if (const char *e = std::getenv("JA_GRID_CAP")) cap = std::min(cap, std::atoi(e));
+#endif
         const int grid = wgs < cap ? wgs : cap;
         if (grid != cap || (grid & 7) != 0) b.xcd_images = 0;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), 0, stream, b);

@@ -26,17 +26,19 @@ for i in range(warm): step(i & 1)
 torch.cuda.synchronize()
 ctx.timer_begin(); step(0); ms = ctx.timer_end()
 fn = lib.jpeg_amd_debug_phase_cycles; fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_size_t]
-buf = np.zeros((4096, 8), np.uint64)
+buf = np.zeros((4096, 16), np.uint64)
 assert fn(buf.ctypes.data, buf.size) == 0
-buf = buf[buf[:, 6] > 0]   # waves that ran (3 072 at three waves per SIMD, 4 096 at four)
+buf = buf[buf[:, 14] > 0]   # waves that ran (3 072 at three waves per SIMD, 4 096 at four)
 print(f"{len(buf)} waves")
-names = ["wait coef DMA", "LDS coef read + chroma DMA issue", "IDCT", "chroma wait + next DMA issue", "hrow prologue + geometry", "8 pixel rows (colour, stage, store)"]
-tot = buf[:, :6].sum(axis=1).astype(np.float64)
+names = ["wait coef DMA", "QUAD: chroma block read + luma DMA issue", "QUAD: chroma IDCT", "QUAD: wait for the others' reads (WAR)", "QUAD: tile write + arrive",
+         "coef read (+ luma DMA wait / chroma tile DMA issue)", "luma IDCT", "chroma wait + next DMA issue", "hrow prologue + geometry",
+         "pixel rows (QUAD: rows 1-6)", "QUAD: wait for the stack's tile (RAW)", "QUAD: rows 0, 7 (all rows otherwise: see above)"]
+tot = buf[:, :12].sum(axis=1).astype(np.float64)
 print(f"step {ms*1e3:.1f} us; per-wave total cycles mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(names):
     c = buf[:, i].astype(np.float64)
     print(f"  {n:40s} {c.mean():10.0f} cycles/wave  {100*c.mean()/tot.mean():5.1f} %   per strip {c.mean()/(16384/len(buf)):8.0f}")
-life, ticks = buf[:, 6].astype(np.float64), buf[:, 7].astype(np.float64)
+life, ticks = buf[:, 14].astype(np.float64), buf[:, 15].astype(np.float64)
 print(f"wave life: mean {life.mean():.0f} max {life.max():.0f} shader cycles = mean {ticks.mean() / 100:.1f} max {ticks.max() / 100:.1f} us of the 100 MHz counter"
       f" -> effective shader clock {100.0 * (life / ticks).mean():.0f} MHz while k_luma_fused runs")
 # per-wave placement and timing (start / end on the chip-wide 100 MHz counter, HW_ID, XCC_ID)

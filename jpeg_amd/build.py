@@ -17,8 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libjpeg_amd.so")
 
-SOURCES = ["kernels_stage.hip", "kernels_fused.hip", "kernels_band.hip", "kernels_encode.hip", "capi.hip", "entropy.cpp", "entropy_encode.cpp"]
-HEADERS = ["dct.hpp", "kernels.hpp", "upsample.hpp"]
+SOURCES = ["kernels_stage.hip", "kernels_fused.hip", "kernels_quad.hip", "kernels_encode.hip", "capi.hip", "entropy.cpp", "entropy_encode.cpp"]
+HEADERS = ["dct.hpp", "kernels.hpp", "upsample.hpp", "fused_common.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-command-line-argument"]
 

@@ -34,9 +34,6 @@ struct jpeg_amd_ctx {
     hipEvent_t file_done[2] = {nullptr, nullptr};     // chunk's pixels are back in pinned memory
     hipEvent_t file_decoded[2] = {nullptr, nullptr};  // chunk's kernels are done (device -> host copy may start)
     hipStream_t file_d2h = nullptr;                   // downloads overlap the next chunk's uploads (full-duplex PCIe)
-    // helper streams / events of the part-pipelined fused decode (created on first use)
-    OverlapLanes lanes;
-    bool lanes_ready = false;
 };
 
 namespace {
@@ -149,23 +146,6 @@ int stage_quanta(jpeg_amd_ctx *ctx, const uint16_t *h_quanta, int ntables, const
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-// streams and events launch_fused_decode pipelines the parts of a call over
-int ensure_lanes(jpeg_amd_ctx *ctx)
-{
-    if (ctx->lanes_ready) return JPEG_AMD_OK;
-    OverlapLanes &l = ctx->lanes;
-    int lo = 0, hi = 0;
-    JA_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi is the numerically lowest = highest priority
-    if (!l.chroma) JA_HIP(ctx, hipStreamCreateWithPriority(&l.chroma, hipStreamNonBlocking, hi));
-    if (!l.luma2) JA_HIP(ctx, hipStreamCreateWithFlags(&l.luma2, hipStreamNonBlocking));
-    if (!l.entered) JA_HIP(ctx, hipEventCreateWithFlags(&l.entered, hipEventDisableTiming));
-    if (!l.luma2_done) JA_HIP(ctx, hipEventCreateWithFlags(&l.luma2_done, hipEventDisableTiming));
-    for (auto &e : l.chroma_done)
-        if (!e) JA_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ctx->lanes_ready = true;
-    return JPEG_AMD_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -237,12 +217,6 @@ int jpeg_amd_ctx_destroy(jpeg_amd_ctx *ctx)
     }
     if (ctx->file_d2h) (void)hipStreamDestroy(ctx->file_d2h);
     if (ctx->file_device) (void)hipFree(ctx->file_device);
-    if (ctx->lanes.chroma) { (void)hipStreamSynchronize(ctx->lanes.chroma); (void)hipStreamDestroy(ctx->lanes.chroma); }
-    if (ctx->lanes.luma2) { (void)hipStreamSynchronize(ctx->lanes.luma2); (void)hipStreamDestroy(ctx->lanes.luma2); }
-    if (ctx->lanes.entered) (void)hipEventDestroy(ctx->lanes.entered);
-    if (ctx->lanes.luma2_done) (void)hipEventDestroy(ctx->lanes.luma2_done);
-    for (auto &e : ctx->lanes.chroma_done)
-        if (e) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -416,17 +390,9 @@ int jpeg_amd_decode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_ima
     if (fused_decode_supported(*L, cosited != 0)) {
         PlaneSet cs{};
         for (int p = 0; p < L->nplanes; ++p) { cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p]; }
-        if (band_decode_supported(*L, n_images)) {
-            JA_HIP(ctx, launch_band_decode(ctx->stream, n_images, *L, cs, QuantaRef{d_quanta, quanta_stride},
-                                           color == JPEG_AMD_COLOR_RGB8, d_pixels, pixel_stride));
-            return JPEG_AMD_OK;
-        }
         JA_TRY(ensure_scratch(ctx, fused_decode_scratch_bytes(*L, n_images)));
-        const bool lanes = fused_decode_wants_lanes();
-        if (lanes) JA_TRY(ensure_lanes(ctx));
         JA_HIP(ctx, launch_fused_decode(ctx->stream, n_images, *L, cs, QuantaRef{d_quanta, quanta_stride},
-                                        color == JPEG_AMD_COLOR_RGB8, ctx->scratch, d_pixels, pixel_stride,
-                                        lanes ? &ctx->lanes : nullptr));
+                                        color == JPEG_AMD_COLOR_RGB8, ctx->scratch, d_pixels, pixel_stride));
         return JPEG_AMD_OK;
     }
 

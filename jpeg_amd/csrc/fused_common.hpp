@@ -1,0 +1,144 @@
+// fused_common.hpp -- device helpers shared by the fused decode kernels (kernels_fused.hip, kernels_quad.hip): division by
+// launch invariants, LDS-DMA issue, the split arrive / wait on LDS counters, the per-phase cycle counters of the
+// development build (-DJA_PHASE_PROFILE, tools/phase_profile.py).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jpeg_amd {
+
+constexpr int kThreads = 256;
+
+// Division by a launch-invariant: q = mulhi(n, floor((2^32 - 1) / d)) is the quotient or one below it for every n < 2^32, one
+// compare fixes it.  The strip walks divide a dozen times per trip (strip -> image, row, column; strips left); as true
+// divisions that is ~400 mostly scalar, serial instructions at the head of every trip.
+struct FastDiv {
+    uint32_t d, m;
+    __device__ __forceinline__ void set(uint32_t div) { d = div; m = 0xffffffffu / div; }
+    __device__ __forceinline__ uint32_t div(uint32_t n, uint32_t &r) const
+    {
+        uint32_t q = __umulhi(n, m);
+        r = n - q * d;
+        if (r >= d) { ++q; r -= d; }
+        return q;
+    }
+};
+
+// One 16-byte-per-lane LDS-DMA: lane l's 16 B at `g` land at LDS byte address lds + 16 l.
+// Issued from inline asm on purpose: hipcc cannot tell which LDS array a DMA targets, so
+// after a __builtin_amdgcn_global_load_lds it makes the NEXT LDS read of any array wait with
+// vmcnt(0) -- i.e. for the prefetch it was supposed to overlap.  Hidden from the compiler, the
+// DMA is only waited for by the explicit s_waitcnt at the top of the next strip.  (Extra
+// outstanding VM operations can only make the compiler's own counted waits longer, never
+// shorter, because loads retire in order.)
+__device__ __forceinline__ void lds_dma16(const void *g, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(lds) : "memory");
+}
+// Same with a scalar 64-bit base + per-lane 32-bit byte offset (no vector address arithmetic).
+__device__ __forceinline__ void lds_dma16_s(uint64_t sbase, uint32_t voff, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
+// The same two without the `nt` hint: for coefficients that neighbouring strips fetch again soon
+// (the chroma blocks around a 4:2:0 strip) and should therefore stay in L2.
+#ifdef JA_X_IN420_NT
+#define JA_KEEP_HINT " nt"
+#else
+#define JA_KEEP_HINT ""
+#endif
+__device__ __forceinline__ void lds_dma16_keep(const void *g, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" JA_KEEP_HINT ::"v"(g), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void lds_dma16_s_keep(uint64_t sbase, uint32_t voff, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" JA_KEEP_HINT ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
+// 4 bytes per lane: lane l's dword lands at LDS byte address lds + 4 l.
+__device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32_t lds)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
+
+// LDS byte address of a __shared__ object (low 32 bits of its flat address), wave-uniform
+template <typename T>
+__device__ __forceinline__ uint32_t lds_address(T *p)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) T *)p);
+}
+
+// Split arrive / wait on an LDS counter (the 4:2:0 stack walk).  The LDS executes one wave's operations in issue order, so a
+// ds_add issued behind the wave's tile writes (or its last tile reads) is performed behind them: no s_waitcnt at the arrive.
+// The waiting side polls with plain LDS reads; what it reads from the tile after the poll has succeeded is issued, and
+// therefore performed, after the read that saw the counter.  Relaxed atomics + compiler barriers on purpose: a release /
+// acquire at workgroup scope would make hipcc wait with vmcnt(0) -- for the coefficient DMA in flight and for the pixel stores.
+__device__ __forceinline__ void lds_arrive(uint32_t *counter, int lane)
+{
+    asm volatile("" ::: "memory");
+    if (lane == 0) (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ uint32_t lds_peek(uint32_t *counter)
+{
+    return __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_wait_ge(uint32_t *counter, uint32_t target)
+{
+#ifdef JA_X_NOSYNC   // experiment (wrong pixels): what do the waits of the stack walk cost?
+    return;
+#endif
+    asm volatile("" ::: "memory");
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)lds_peek(counter)) < target) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+// the same when the counter was already read a while ago (`seen`, any lane's copy): the common case costs no LDS round trip
+__device__ __forceinline__ void lds_wait_ge_seen(uint32_t *counter, uint32_t target, uint32_t seen)
+{
+#ifdef JA_X_NOSYNC
+    return;
+#endif
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)seen) < target) lds_wait_ge(counter, target);
+    asm volatile("" ::: "memory");
+}
+
+#ifdef JA_PHASE_PROFILE
+// development aid (tools/phase_profile.py): wall cycles each wave spends per phase of a strip
+constexpr int kPhaseSlots = 16;   // 0..13 phases, 14 the wave's life in shader cycles, 15 in ticks of the 100 MHz counter
+// each translation unit that profiles holds its own copy (no relocatable device code): JA_PHASE_STORAGE at namespace scope
+#define JA_PHASE_STORAGE                                                                                \
+    __device__ unsigned long long g_phase_cycles[4096 * kPhaseSlots];                                   \
+    __device__ unsigned long long g_wave_info[4096 * 4];   /* start tick, end tick (100 MHz counter), HW_ID, XCC_ID */
+#define JA_PHASE_DECL                                                                                   \
+    unsigned long long phase_acc[kPhaseSlots] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      \
+    unsigned long long t_prev = __builtin_readcyclecounter();                                           \
+    const unsigned long long t_first = t_prev, r_first = __builtin_amdgcn_s_memrealtime();
+#define JA_PHASE(i)                                                       \
+    {                                                                     \
+        const unsigned long long t_now = __builtin_readcyclecounter();    \
+        phase_acc[i] += t_now - t_prev;                                   \
+        t_prev = t_now;                                                   \
+    }
+#define JA_PHASE_FLUSH(slot, lane)                                                                       \
+    {                                                                                                    \
+        phase_acc[14] = __builtin_readcyclecounter() - t_first;                                          \
+        phase_acc[15] = __builtin_amdgcn_s_memrealtime() - r_first;                                      \
+        if ((lane) == 0 && (slot) < 4096) {                                                              \
+            for (int i_ = 0; i_ < kPhaseSlots; ++i_) g_phase_cycles[(slot) * kPhaseSlots + i_] = phase_acc[i_]; \
+            unsigned long long *wi_ = g_wave_info + (slot) * 4;                                          \
+            wi_[0] = r_first; wi_[1] = r_first + phase_acc[15];                                          \
+            unsigned hw_, xcc_;                                                                          \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                            \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                          \
+            wi_[2] = hw_; wi_[3] = xcc_ & 15u;                                                           \
+        }                                                                                                \
+    }
+#else
+#define JA_PHASE_STORAGE
+#define JA_PHASE_DECL
+#define JA_PHASE(i)
+#define JA_PHASE_FLUSH(slot, lane)
+#endif
+
+}  // namespace jpeg_amd

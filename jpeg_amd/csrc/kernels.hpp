@@ -62,29 +62,15 @@ hipError_t launch_unpack(hipStream_t stream, const uint16_t *d_rect, size_t npix
 // with full-factor luma and 1x / 2x subsampled chroma, centred upsampling.
 bool       fused_decode_supported(const jpeg_amd_layout &layout, bool cosited);
 size_t     fused_decode_scratch_bytes(const jpeg_amd_layout &layout, int n_images);
-// Helper streams and events a context lends to launch_fused_decode so that the two launches of a
-// 4:2:0 / 4:4:0 decode can be pipelined over PARTS of the call (groups of images of a batch, the upper and
-// lower half of one large image): k_chroma_idct of part p + 1 runs beside k_luma_fused of part p, and
-// consecutive parts' k_luma_fused alternate between two streams so that the thin last round of one overlaps
-// the first of the next.  Everything is joined back into the caller's stream before the call returns.
-struct OverlapLanes {
-    static constexpr int kMaxParts = 8;
-    hipStream_t chroma = nullptr;             // k_chroma_idct of every part, in order (high priority)
-    hipStream_t luma2 = nullptr;              // k_luma_fused of the odd parts (the even parts' use the caller's stream)
-    hipEvent_t entered = nullptr;             // caller's stream at the start of the call: inputs ready, scratch free
-    hipEvent_t chroma_done[kMaxParts] = {};   // part p's chroma samples are in the scratch planes
-    hipEvent_t luma2_done = nullptr;
-};
-bool       fused_decode_wants_lanes();   // JPEG_AMD_OVERLAP=1 (off by default: measured slower, see kernels_fused.hip)
 hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &layout,
                                const PlaneSet &coef, QuantaRef q, bool rgb, void *scratch,
-                               uint8_t *d_pixels, size_t pixel_stride, const OverlapLanes *lanes = nullptr);
+                               uint8_t *d_pixels, size_t pixel_stride);
 
-// The same for ycc8 4:2:0 in ONE launch with no chroma intermediate in HBM (kernels_band.hip): a wave
-// walks down a band of 64 luma blocks and keeps the chroma samples it needs in LDS.  Chosen when the
-// call has enough independent pieces for every resident wave (large images, batches).
-bool       band_decode_supported(const jpeg_amd_layout &layout, int n_images);
-hipError_t launch_band_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &layout,
+// ycc8 4:2:0 in ONE launch with no chroma intermediate in HBM (kernels_quad.hip): the waves of a workgroup decode a
+// stack of vertically adjacent strips together and share one chroma tile in LDS.  Any image size; launch_fused_decode
+// sends every 4:2:0 call here.
+bool       quad_decode_supported(const jpeg_amd_layout &layout);
+hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &layout,
                               const PlaneSet &coef, QuantaRef q, bool rgb, uint8_t *d_pixels,
                               size_t pixel_stride);
 

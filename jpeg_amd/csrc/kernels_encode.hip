@@ -459,11 +459,14 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
 
 }  // namespace
 
-// development switch: JPEG_AMD_ENC_TY=8 / 16 forces the tile height of the grey / 4:2:0 encode kernels
+// development switch (-DJA_X_ENC_TY=8 / 16, tools/build_exp.sh): forces the tile height of the grey / 4:2:0 encode kernels
 static int encode_ty_override()
 {
-    static const int v = [] { const char *e = std::getenv("JPEG_AMD_ENC_TY"); return e ? std::atoi(e) : 0; }();
-    return v;
+#ifdef JA_X_ENC_TY
+    return JA_X_ENC_TY;
+#else
+    return 0;
+#endif
 }
 
 bool fused_encode_supported(const jpeg_amd_layout &L)

@@ -1,0 +1,616 @@
+// kernels_quad.hip -- ycc8 4:2:0 Spectral -> YCbCr / RGB bytes in ONE launch, no intermediate in HBM (the "stack walk").
+//
+// Replaces idct() -> interleaved(cosite: false) -> unpack(as:) (decode.swift:4154, 4182, 4294) for three-plane images
+// whose luma has the factors (2, 2) and whose chroma planes (1, 1): BASELINE.json configs[2] (8192 x 8192) and configs[4]
+// (batches of 1920 x 1080).  6 B/px of algorithmic traffic: 128 B per coefficient block in, 3 B per pixel out.
+//
+// Work decomposition.  One 8 x 8 block per work-item (both IDCT passes and both transposes of decode.swift:3971-4099 are
+// register renames).  A STRIP is BX x BY luma blocks with BX * BY = 64 -- 32 x 2 (256 x 16 px) or 16 x 4 (128 x 32 px) --
+// and one wave's unit of work.  The bilinear chroma filter couples every pixel row to the chroma sample row above / below
+// (decode.swift:4243-4257), so QS vertically adjacent strips form a STACK that the QS waves of a workgroup decode
+// together (4 strips of 32 x 2, or 2 strips of 16 x 4: 256 x 64 / 128 x 64 px), sharing ONE chroma tile in LDS:
+//   - chroma pass: a wave transforms the 32 chroma blocks under its own strip, its share of the blocks whose edge sample
+//     row lies above / below the stack, and the neighbour blocks left / right of its rows (56-60 work-items busy), and
+//     writes the samples as bytes into the tile;
+//   - luma pass: dequantise + IDCT of the strip's 64 luma blocks;
+//   - pixel rows: upsample from the tile (centred 2x: weights 1/4, 3/4), colour matrix, pack, store whole 16-byte chunks
+//     of contiguous row segments through a small LDS staging row.
+// Between the waves of a stack there is no barrier, only two monotonic LDS counters: a wave ARRIVES ("my samples are in
+// the tile") right after its chroma pass and checks the counter a luma transform and six pixel rows later, before the two
+// pixel rows that read another wave's samples (rows are processed in the order 1..6, 0, 7); the second counter keeps the
+// tile from being overwritten while a neighbour still reads it.
+// Coefficients arrive by LDS-DMA (global_load_lds_dwordx4) one phase ahead, into the wave's 8 KiB buffer: the luma blocks
+// during the chroma transform, the NEXT stack's chroma blocks during the luma transform and the pixel rows.
+//
+// Exactness: dct.hpp op for op (-ffp-contract=off); upsample.hpp for the exact shortcuts of the filter (small-integer
+// arithmetic, floor-free rounding); the colour matrix as in k_luma_fused (tests/test_colour_rounding.py enumerates every
+// input).  Strips, stacks and tile columns that reach past the image or the plane are handled in place (clamped fetches,
+// predicated stores, the reference's index clamps repaired in the tile), so any image size takes this kernel.
+//
+// Development switches (never defined in the product build): JA_PHASE_PROFILE, JA_X_NOSYNC, JA_X_NOCIDCT, JA_X_NOIDCT,
+// JA_X_NOSTORE, JA_X_STAGGER=<cycles>.
+#pragma clang fp contract(off)
+
+#include "dct.hpp"
+#include "fused_common.hpp"
+#include "kernels.hpp"
+#include "upsample.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace jpeg_amd {
+
+namespace {
+
+JA_PHASE_STORAGE
+
+struct QuadArgs {
+    const int16_t *coef[3];        // Y, Cb, Cr coefficient planes [units_y][units_x][64], zigzag
+    size_t coef_stride[3];         // elements between images
+    const uint16_t *quanta;
+    size_t quanta_stride;
+    int qi[3];
+    int ux, uy;                    // luma units
+    int uxc, uyc;                  // chroma units
+    int W, H;
+    uint8_t *out;
+    size_t out_stride;
+    int tiles_x;                   // strips per strip row
+    int stacks_per_image;          // tiles_x * stack rows
+    int nstacks;                   // of the whole call
+};
+
+template <int BX> struct QuadShape {
+    static constexpr int BY = 64 / BX;
+    static constexpr int QS = BX == 32 ? 4 : 2;           // strips (= waves) per stack
+    static constexpr int QG = (kThreads / 64) / QS;       // stacks per workgroup
+};
+
+// MODE: 0 = YCbCr bytes, 1 = RGB bytes.  FAST: W % 16 == 0 and 16-byte aligned rows, so every 16-byte chunk of a row
+// segment is entirely inside the image or entirely outside (no byte-wise tail code).
+template <int MODE, int BX, bool FAST>
+__global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
+{
+    constexpr int BY = QuadShape<BX>::BY, QS = QuadShape<BX>::QS, QG = QuadShape<BX>::QG;
+    constexpr int NW = kThreads / 64;
+    constexpr int CW = BX * 4, CR = BY * 4;               // chroma samples per strip row, chroma sample rows under a strip
+    constexpr int CBW = BX / 2, CBR = BY / 2;             // chroma blocks under a strip
+    constexpr int PITCH = CW / 4 + 2;                     // dwords per tile row: one halo dword left, the samples, one right
+    constexpr int QROWS = QS * CR + 2;                    // sample rows of a stack's tile: halo, QS x CR rows, halo (34)
+    constexpr int PLANE = QROWS * PITCH;                  // dwords per plane of the tile
+    constexpr int SEG_DW = BX * 6;                        // one pixel row of one block row: 24 B per block
+    constexpr int CPS = SEG_DW / 4;                       // 16-byte chunks per such segment
+    // what work-item b of the wave at position qp transforms in the chroma pass:
+    //   0..31            the strip's own blocks: plane b >> 4, then row-major (b & 15) over CBR rows of CBW columns
+    //   32..47           the block row above the stack (first half of the stack's waves) or below it (second half), column
+    //                    b & (CBW - 1); the plane is the wave's parity (four waves: 16 columns each) or bit 3 of b (two waves)
+    //   48..48+4 CBR-1   left / right neighbours of the own rows: row (b - 48) >> 2, plane bit 1, side bit 0
+    //   then 4           the same two columns of the row above (first wave) / below (last wave) the stack: corner samples
+    constexpr int QCORN0 = 48 + 4 * CBR, QEND = QCORN0 + 4;
+    constexpr int NDMA_C = (QEND + 7) / 8;                // LDS-DMA instructions of a chroma pass (8 blocks each)
+
+    __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];   // 8 KiB per wave
+    __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
+    __shared__ uint32_t qtile[QG * 2 * PLANE];            // one tile per stack; row 0: halo above, rows 1 + CR p ...: wave p, last row: halo below
+    __shared__ float sqw[NW][3][64];                      // modulated tables: Y, Cb, Cr
+    // per stack two monotonic counters.  [0] "ready": a wave has written its samples of this trip into the tile;
+    // [1] "done": a wave has read the last sample of this trip that another wave wrote.
+    __shared__ uint32_t qsync[2 * QG];
+
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // strip math stays scalar
+    const int qp = wave % QS, qg = wave / QS;             // position in the stack, stack of the workgroup
+    uint32_t *coef_w = coefbuf[wave], *stage_w = stage[wave];
+    const uint32_t coef_lds = lds_address(coef_w);
+    uint32_t *qt = qtile + qg * 2 * PLANE;
+    uint32_t *sc = qt + CR * qp * PITCH;                  // this wave's window: row 0 = the sample row above its own rows
+    uint32_t *ready = &qsync[2 * qg], *done = &qsync[2 * qg + 1];
+
+    if (threadIdx.x < 2 * QG) qsync[threadIdx.x] = 0;
+    __syncthreads();   // the only workgroup barrier of the walk
+
+    FastDiv fd_spi, fd_tx;
+    fd_spi.set((uint32_t)a.stacks_per_image); fd_tx.set((uint32_t)a.tiles_x);
+    // trip t of this workgroup: stack (blockIdx.x + t gridDim.x) QG + qg -> image, strip row of this wave, strip column
+    auto stack_of = [&](int t) -> int { return ((int)blockIdx.x + t * (int)gridDim.x) * QG + qg; };
+    auto locate = [&](int q, int &img, int &syi, int &sxi) {
+        uint32_t rem, col;
+        img = (int)fd_spi.div((uint32_t)q, rem);
+        syi = QS * (int)fd_tx.div(rem, col) + qp;
+        sxi = (int)col;
+    };
+    const int trips = (a.nstacks - qg + (int)gridDim.x * QG - 1 - (int)blockIdx.x * QG) / ((int)gridDim.x * QG);   // stacks this wave's pair walks
+    if (stack_of(0) >= a.nstacks) return;
+
+    auto quad_block = [&](int b, int syi, int sxi, int &pl, int &bx, int &by) {
+        const int top = syi - qp;                                           // strip row of the stack's first strip
+        const int above_row = CBR * top - 1, below_row = CBR * (top + QS);  // chroma block rows (clamped by the caller)
+        if (b < 32) { const int idx = b & 15; pl = b >> 4; bx = CBW * sxi + idx % CBW; by = CBR * syi + idx / CBW; }
+        else if (b < 48) { pl = BX == 32 ? (qp & 1) : ((b >> 3) & 1); bx = CBW * sxi + (b & (CBW - 1)); by = qp < QS / 2 ? above_row : below_row; }
+        else {
+            const int j = b < QCORN0 ? b - 48 : b - QCORN0;
+            pl = (j >> 1) & 1; bx = (j & 1) ? CBW * sxi + CBW : CBW * sxi - 1;
+            by = b < QCORN0 ? CBR * syi + (j >> 2) : (qp == 0 ? above_row : below_row);
+        }
+    };
+    // LDS-DMA of a pass's blocks: instruction i moves 64 x 16 B; slot u = 64 i + lane holds chunk (u & 7) ^ ((b >> 1) & 7)
+    // of block b = u >> 3 -- the XOR on the SOURCE address makes the later per-work-item ds_read_b128 (stride 128 B)
+    // bank-conflict-free.  Where the eight blocks of an instruction are neighbours in a block row, the block index is
+    // scalar and only the lane's place inside the group is per lane (`ve`; odd i: chunk ^ 4).
+    auto dma_chroma = [&](int q, int lane) {
+        int img, syi, sxi;
+        locate(q, img, syi, sxi);
+        const uint32_t l3 = lane >> 3;
+        const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+        int first_general = 0;
+        if (CBW * sxi + CBW <= a.uxc) {   // wave-uniform: the strip's chroma columns lie inside the plane
+            const int top = syi - qp;
+            const int halo_row = min(max(qp < QS / 2 ? CBR * top - 1 : CBR * (top + QS), 0), a.uyc - 1);   // missing rows: fetched, not used
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int pl, row, col0;
+                if constexpr (BX == 32) { pl = i < 4 ? i >> 1 : (qp & 1); row = i < 4 ? syi : halo_row; col0 = 16 * sxi + 8 * (i & 1); }
+                else { pl = i < 4 ? i >> 1 : (i & 1); row = i < 4 ? 2 * syi + (i & 1) : halo_row; col0 = 8 * sxi; }
+                row = min(row, a.uyc - 1);
+                const uint64_t sb = reinterpret_cast<uint64_t>(a.coef[1 + pl] + img * a.coef_stride[1 + pl]) +
+                                    ((uint64_t)((uint32_t)row * (uint32_t)a.uxc + (uint32_t)col0) << 7);
+                lds_dma16_s_keep(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+            }
+            first_general = 6;
+        }
+#pragma unroll
+        for (int i = 0; i < NDMA_C; ++i) {
+            if (i < first_general) continue;
+            const int b = 8 * i + (lane >> 3);
+            int pl, bx, by;
+            if (BX == 32 && i == 6) {   // sides (48..51) and corners (52..55): the same map as quad_block with fewer branches
+                const int top = syi - qp;
+                pl = (b >> 1) & 1; bx = (b & 1) ? 16 * sxi + 16 : 16 * sxi - 1; by = b < 52 ? syi : (qp < 2 ? top - 1 : top + QS);
+            } else {
+                quad_block(b, syi, sxi, pl, bx, by);
+            }
+            by = min(max(by, 0), a.uyc - 1);   // missing rows: fetched, not used
+            const int16_t *cbase = a.coef[1 + pl] + img * a.coef_stride[1 + pl];
+            const uint32_t blk = (bx >= 0 && bx < a.uxc) ? (uint32_t)by * a.uxc + bx : 0u;
+            const int c = (lane & 7) ^ ((b >> 1) & 7);
+            lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+        }
+    };
+    auto dma_luma = [&](int img, int syi, int sxi, int lane) {
+        const int16_t *base = a.coef[0] + img * a.coef_stride[0];
+        if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {   // interior strip (wave-uniform)
+            const uint32_t l3 = lane >> 3;
+            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t blk0 = (uint32_t)(BY * syi + i / (BX / 8)) * a.ux + sxi * BX + 8 * (i % (BX / 8));
+                const uint64_t sb = reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7);
+                lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = 8 * i + (lane >> 3);  // block within the strip: column b % BX, row b / BX
+            const int bx = sxi * BX + (b & (BX - 1)), by = BY * syi + (int)((unsigned)b / BX);
+            // blocks outside the plane fetch block 0; the store predicate discards their pixels
+            const uint32_t blk = (bx < a.ux && by < a.uy) ? (uint32_t)by * a.ux + bx : 0u;
+            const int c = (lane & 7) ^ ((b >> 1) & 7);
+            lds_dma16(reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+        }
+    };
+
+#ifdef JA_X_STAGGER   // experiment: the three workgroups of a CU start a third of a strip apart
+    for (int d = (int)(blockIdx.x / 256u) * (JA_X_STAGGER); d > 0; d -= 64 * 100) __builtin_amdgcn_s_sleep(100);
+#endif
+    dma_chroma(stack_of(0), lane0);
+    int img_of_table = -1;
+    int stores_behind_dma = 0;  // wave-uniform
+    JA_PHASE_DECL
+
+    for (int trip = 0; trip < trips; ++trip) {
+        // Launder the lane id once per strip: everything below that depends only on the lane is
+        // cheap to recompute, but hoisted out of this loop it would pin ~60 VGPRs for good.
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int lbx = lane & (BX - 1), seg = (int)((unsigned)lane / BX);
+        int img, syi, sxi;
+        locate(stack_of(trip), img, syi, sxi);
+
+        // ---- modulated tables (only when the image changes) ----
+        if (img != img_of_table) {
+            const int qk = lane & 7, qh = lane >> 3;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                sqw[wave][p][lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi[p] + zigzag_of(qk, qh)]);
+            img_of_table = img;
+        }
+
+        // ---- the chroma pass's coefficients: wait for the DMA, read 8 x 16 B (swizzled).  VM operations retire in issue
+        //      order and the DMA was issued BEFORE the previous strip's pixel stores: when that strip took the branch-free
+        //      store path (exactly 2 store instructions per pixel row) only the DMA has to be waited for ----
+        if (stores_behind_dma == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        JA_PHASE(0)
+        // The scheduler of a SIMD issues its oldest ready wave first.  From the start of a strip to the arrival at the
+        // "ready" counter a wave runs at the top priority (whoever arrives late is waited for by up to three others);
+        // after it at most at priority 2, by strips left -- laggards catch up and the waves of a SIMD leave together.
+        __builtin_amdgcn_s_setprio(3);
+        uint32_t w[32];
+        auto read_block = [&]() {
+            const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
+            const int sw = (lane >> 1) & 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 v = cw[i ^ sw];
+                w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+        };
+        read_block();
+        const uint32_t done_seen = lds_peek(done);   // checked after the transform; read here so that the check costs no round trip
+        // w holds the chroma pass's block; the luma blocks of the strip follow it into the buffer
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_luma(img, syi, sxi, lane);
+        JA_PHASE(1)
+
+        const int top = syi - qp;
+        const bool stack_above = top > 0, stack_below = CBR * (top + QS) < a.uyc;   // uniform over the stack
+        const bool has_left = sxi > 0, has_right = CBW * sxi + CBW < a.uxc;
+        const int first_bad = (a.uxc << 1) - sxi * (CW / 4) + 1;   // first tile dword past the plane (PITCH - 1 at a full last tile)
+        {
+            int pl, bx_, by_;
+            quad_block(lane, syi, sxi, pl, bx_, by_);
+            float g[64];
+#ifdef JA_X_NOCIDCT   // experiment (wrong pixels): the walk without the arithmetic of its chroma transform
+#pragma unroll
+            for (int i = 0; i < 64; ++i) g[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff) + sqw[wave][1 + pl][i];
+#else
+            idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+#endif
+            // clamp [0, 255] + truncate == saturating convert of floor(v); every work-item packs its whole block (one
+            // instruction stream for the three kinds of block), what is stored where differs
+            uint32_t pk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                uint32_t d = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) d = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[4 * i + x]), x, d);
+                pk[i] = d;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pk[i]));
+            JA_PHASE(2)
+            // everyone has read the previous trip's tile before anyone overwrites it: the others signalled "done" two pixel
+            // rows before the end of their previous strip, more than a transform ago -- this rarely waits
+            lds_wait_ge_seen(done, (uint32_t)(QS * trip), done_seen);
+            JA_PHASE(3)
+            uint32_t *tile = qt + pl * PLANE;
+            if (lane < 32) {
+                const int idx = lane & 15;
+                uint32_t *dst = tile + (1 + CR * qp + 8 * (idx / CBW)) * PITCH + 1 + 2 * (idx % CBW);
+#pragma unroll
+                for (int y = 0; y < 8; ++y) { dst[y * PITCH] = pk[2 * y]; dst[y * PITCH + 1] = pk[2 * y + 1]; }
+            } else if (lane < 48) {
+                const bool above = qp < QS / 2;
+                if (above ? stack_above : stack_below) {
+                    uint32_t *dst = tile + (above ? 0 : QROWS - 1) * PITCH + 1 + 2 * (lane & (CBW - 1));
+                    dst[0] = above ? pk[14] : pk[0];     // last row of the block above / first row of the block below
+                    dst[1] = above ? pk[15] : pk[1];
+                }
+            } else if (lane < QEND) {
+                const int j = lane < QCORN0 ? lane - 48 : lane - QCORN0, side = j & 1;
+                // the neighbour's edge sample, replicated: first column of the block to the right, last of the block to the left
+                auto rep = [&](int y) -> uint32_t { return side ? (pk[2 * y] & 0xffu) * 0x01010101u : (pk[2 * y + 1] >> 24) * 0x01010101u; };
+                if (side ? has_right : has_left) {
+                    uint32_t *col = tile + (side ? PITCH - 1 : 0);
+                    if (lane < QCORN0) {
+#pragma unroll
+                        for (int y = 0; y < 8; ++y) col[(1 + CR * qp + 8 * (j >> 2) + y) * PITCH] = rep(y);
+                    } else if (qp == 0 && stack_above) col[0] = rep(7);
+                    else if (qp == QS - 1 && stack_below) col[(QROWS - 1) * PITCH] = rep(0);
+                }
+            }
+        }
+        // the plane's left / right edge: the reference clamps the sample index (decode.swift:4245) -- own rows here, the two
+        // halo rows after the wait for the tile (their samples come from other waves)
+        auto fix_columns = [&](uint32_t *row) {
+            if (!has_left) row[0] = (row[1] & 0xffu) * 0x01010101u;
+            if (first_bad < PITCH) {
+                const uint32_t last = (row[first_bad - 1] >> 24) * 0x01010101u;
+                for (int c = first_bad; c < PITCH; ++c) row[c] = last;
+            }
+        };
+        if (!has_left || first_bad < PITCH) {
+            if (lane < 2 * CR) fix_columns(qt + (lane / CR) * PLANE + (1 + CR * qp + lane % CR) * PITCH);
+        }
+        // this wave's samples are in the tile: arrive, do not wait
+        lds_arrive(ready, lane);
+        JA_PHASE(4)
+        {
+            const int rem = trips - 1 - trip;   // strips after this one
+            if (rem >= 2) __builtin_amdgcn_s_setprio(2);
+            else if (rem == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        read_block();
+        // ---- the coefficient buffer is consumed: prefetch the next stack's chroma pass into it.  From here to the end of
+        //      the strip only stores are issued, so nothing waits on the DMA. ----
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (trip + 1 < trips) dma_chroma(stack_of(trip + 1), lane);
+        __builtin_amdgcn_sched_barrier(0);
+        JA_PHASE(5)
+
+        // ---- luma: dequantise + IDCT, clamp + truncate (decode.swift:4121-4122), kept as integer-valued floats ----
+        float yv[64];
+#ifdef JA_X_NOIDCT  // experiment: how long is a strip without the IDCT arithmetic?
+#pragma unroll
+        for (int i = 0; i < 64; ++i) yv[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff);
+#else
+        idct_block(w, sqw[wave][0], 128.5f, yv);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) yv[i] = floorf(__builtin_amdgcn_fmed3f(yv[i], 0.0f, 255.0f));
+#endif
+        // pin the IDCT here (LLVM otherwise sinks it into the pixel rows)
+#pragma unroll
+        for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(yv[i]));
+        __builtin_amdgcn_sched_barrier(0);
+        JA_PHASE(6)
+
+        // ---- chroma rows, produced just in time from the tile.  Patch row j of a block: window row seg (8 / 2) + j;
+        //      the LDS reads (hraw) and the conversion + horizontal interpolation (hconv) are separate so that the reads
+        //      can be issued well ahead of their use ----
+        auto hraw = [&](int pl, int j, uint32_t (&r)[3]) {
+            const uint32_t *row = sc + pl * PLANE + (seg * 4 + j) * PITCH;
+            r[0] = row[lbx]; r[1] = row[1 + lbx]; r[2] = row[2 + lbx];
+        };
+        auto hconv = [&](const uint32_t (&r)[3], float (&o)[8]) {   // samples enter as 2^15 + p + 1/32 (upsample.hpp)
+            const float p[6] = {ubyte_magic<3>(r[0]), ubyte_magic<0>(r[1]), ubyte_magic<1>(r[1]),
+                                ubyte_magic<2>(r[1]), ubyte_magic<3>(r[1]), ubyte_magic<0>(r[2])};
+            lerp_row_2x(p, o);
+        };
+        // final chroma value of one pixel from the vertically combined sum: floor(v / 16 + 1/2) [- 128], without a floor
+        auto finish = [&](float v) -> float {
+            return __builtin_fmaf(v, 0.0625f, kMagic - 32768.0f - (MODE == 1 ? 128.0f : 0.0f)) - kMagic;
+        };
+        // slot 0 = patch row 1 (kept for pixel row 0), slots 1 / 2 the sliding pair
+        float hw[2][3][8];
+        uint32_t rawn[2][3], raw0[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            uint32_t r1[3], r2[3];
+            hraw(pl, 1, r1); hraw(pl, 2, r2); hraw(pl, 3, rawn[pl]);
+            hconv(r1, hw[pl][0]); hconv(r2, hw[pl][1]);
+        }
+
+        // ---- store geometry: per pixel row the strip's BY segments are 96 chunks of 16 B; a lane stores chunk `lane` (and
+        //      lanes 0..31 also chunk 64 + lane).  Both store instructions of a row cover whole 128-byte lines. ----
+        const int tile_px = min(BX * 8, a.W - BX * 8 * sxi);    // pixels of this strip inside the image
+        const int nb = 3 * tile_px;                              // bytes per row segment to write
+        const uint32_t pitch = 3u * a.W;
+        uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(8 * BY * syi) * a.W + BX * 8 * sxi) * 3;
+        int sg0, sg1;   // segments of chunk `lane` and of chunk 64 + lane (the latter for lanes 0..31)
+        if constexpr (BX == 32) { sg0 = lane >= 48 ? 1 : 0; sg1 = 1; }
+        else { sg0 = (int)((unsigned)lane / CPS); sg1 = (int)((64u + (unsigned)lane) / CPS); }
+        const int j0 = lane - CPS * sg0, j1 = 64 + lane - CPS * sg1;
+        const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = sg1 * 8u * pitch + 16u * j1;
+        const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
+        const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
+        stores_behind_dma = (FAST && full) ? 16 : 0;
+        JA_PHASE(7)
+
+        // One pixel row of the strip's BY block rows at a time, software-pipelined: row y is staged (ds_write) and read
+        // back as 16-byte chunks (ds_read) right after its arithmetic, but the chunks are stored only after the arithmetic
+        // of the next row.
+        uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = make_uint4(0, 0, 0, 0);   // chunks of the previous pixel row
+        auto put = [&](uint8_t *o, const uint4 &v, int j) {
+            if constexpr (FAST) {
+                store_nt16(o, v);   // streaming output, never re-read
+            } else {
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+                for (int k = 0; k < 16; ++k)
+                    if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
+            }
+        };
+        auto store_row = [&](int yy) {
+            uint8_t *rowp = strip_out + (size_t)yy * pitch;   // scalar
+#ifdef JA_X_NOSTORE  // experiment: everything but the global stores
+            if (a.W < 0)
+#endif
+            if (FAST && full) {
+                put(rowp + voff0, pv0, j0);
+                if (lane < 32) put(rowp + voff1, pv1, j1);
+            } else {
+                if (col0 && 8 * BY * syi + 8 * sg0 + yy < a.H) put(rowp + voff0, pv0, j0);
+                if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);
+            }
+        };
+        // pixel row y of the work-item's block: vertical interpolation (the nearer patch row weighs 3), colour, pack; then the
+        // row's traffic: the previous row's stores, this row's staging
+        auto step = [&](int y, int near, int far, int prev) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            float cv[2][8];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int x = 0; x < 8; ++x) cv[pl][x] = finish(w31(hw[pl][near][x], hw[pl][far][x]));
+            uint32_t d[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float yy = yv[8 * y + x];
+                float c0, c1, c2;
+                if constexpr (MODE == 1) {
+                    const float pb = cv[0][x], pr = cv[1][x];
+                    // jpeg.swift:441-453.  v_cvt_pk_u8_f32 rounds to nearest-even and saturates; the reference clamps and
+                    // TRUNCATES.  R, B: kTruncBias added to y turns round-to-nearest into truncation for every (y, c), one
+                    // FMA each; G: floor(fma(m_cr, cr, fma(m_cb, cb, y))).  Every input triple is enumerated in
+                    // tests/test_colour_rounding.py.
+                    const float yb = yy + kTruncBias;
+                    c0 = __builtin_fmaf(1.40200f, pr, yb);
+                    c1 = floorf(__builtin_fmaf(-0.71414f, pr, __builtin_fmaf(-0.34414f, pb, yy)));
+                    c2 = __builtin_fmaf(1.77200f, pb, yb);
+                } else {
+                    c0 = yy; c1 = cv[0][x]; c2 = cv[1][x];
+                }
+                // saturating convert of an integer-valued float == clamp [0, 255] + truncate
+                d[(3 * x + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c0, (3 * x + 0) & 3, d[(3 * x + 0) >> 2]);
+                d[(3 * x + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c1, (3 * x + 1) & 3, d[(3 * x + 1) >> 2]);
+                d[(3 * x + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c2, (3 * x + 2) & 3, d[(3 * x + 2) >> 2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (prev >= 0) store_row(prev);
+            uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
+            sw[0] = make_uint2(d[0], d[1]);
+            sw[1] = make_uint2(d[2], d[3]);
+            sw[2] = make_uint2(d[4], d[5]);
+            pv0 = *reinterpret_cast<const uint4 *>(stage_w + 4 * lane);
+            pv1 = *reinterpret_cast<const uint4 *>(stage_w + 4 * (64 + (lane & 31)));
+        };
+        // Rows in the order 1 2 3 4 5 6 | 0 7: only row 0 of the strip's first block row reads the sample row above the wave's
+        // own (patch row 0) and only row 7 of its last block row the one below (patch row 5) -- samples other waves produce.
+        step(1, 0, 1, -1);                                    // patch rows 1 (near), 2
+        step(2, 1, 0, 1);                                     // 2, 1
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][2]);   // patch row 3
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) hraw(pl, 4, rawn[pl]);
+        step(3, 1, 2, 2);                                     // 2, 3
+        step(4, 2, 1, 3);                                     // 3, 2
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][1]);   // patch row 4 (row 2 is dead)
+        const uint32_t ready_seen = lds_peek(ready);
+        step(5, 2, 1, 4);                                     // 3, 4
+        JA_PHASE(8)
+        // ---- the stack's tile is complete: everyone's samples of this trip are in it ----
+        lds_wait_ge_seen(ready, (uint32_t)(QS * (trip + 1)), ready_seen);
+        JA_PHASE(9)
+        {
+            // the sample row above the wave's first / below its last, where it is not another wave's: image top / bottom (a
+            // missing row is the nearest own row, decode.swift:4246), and the edge columns of the stack's two halo rows
+            // (decode.swift:4245; their samples came from other waves).  Only this wave reads the rows it repairs.
+            const int rows_avail = 8 * (a.uyc - CBR * syi);   // chroma sample rows of the plane from the first one under this strip
+            auto copy_row = [&](int dst, int src) {          // rows of the wave's window, both planes
+                for (int d = lane; d < 2 * PITCH; d += 64) {
+                    uint32_t *col = sc + (d >= PITCH ? PLANE + d - PITCH : d);
+                    col[dst * PITCH] = col[src * PITCH];
+                }
+            };
+            if (syi == 0) copy_row(0, 1);
+            else if (qp == 0 && (!has_left || first_bad < PITCH) && lane < 2) fix_columns(qt + lane * PLANE);
+            if (rows_avail > 0 && rows_avail <= CR) copy_row(rows_avail + 1, rows_avail);
+            else if (qp == QS - 1 && (!has_left || first_bad < PITCH) && lane < 2) fix_columns(qt + lane * PLANE + (QROWS - 1) * PITCH);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) { hraw(pl, 0, raw0[pl]); hraw(pl, 5, rawn[pl]); }
+        // those were this trip's last reads of samples another wave wrote (the LDS performs them before the add)
+        lds_arrive(done, lane);
+        step(6, 1, 2, 5);                                     // 4, 3
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) hconv(raw0[pl], hw[pl][2]);   // patch row 0 (row 3 is dead)
+        step(0, 0, 2, 6);                                     // 1, 0
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][2]);   // patch row 5
+        step(7, 1, 2, 0);                                     // 4, 5
+        __builtin_amdgcn_sched_barrier(0);
+        store_row(7);
+        JA_PHASE(10)
+    }
+    JA_PHASE_FLUSH((int)blockIdx.x * NW + wave, lane0)
+}
+
+// Persistent grid = what is resident at once (LDS-bound: three workgroups per CU).
+template <int MODE, int BX, bool FAST>
+int quad_resident_workgroups()
+{
+    static int cached = 0;  // one per instantiation
+    if (cached == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_quad420<MODE, BX, FAST>, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached = per_cu * cus;
+    }
+    return cached;
+}
+
+template <int MODE, int BX, bool FAST>
+hipError_t launch_quad(hipStream_t stream, const QuadArgs &a)
+{
+    int cap = quad_resident_workgroups<MODE, BX, FAST>();
+#ifdef JA_PHASE_PROFILE   // development aid: JA_GRID_CAP=256 runs one workgroup per CU (a wave alone on its SIMD)
+    if (const char *e = std::getenv("JA_GRID_CAP")) cap = std::min(cap, std::atoi(e));
+#endif
+    const int wgs = (a.nstacks + QuadShape<BX>::QG - 1) / QuadShape<BX>::QG;
+    hipLaunchKernelGGL((k_quad420<MODE, BX, FAST>), dim3(std::min(wgs, cap)), dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+#ifdef JA_PHASE_PROFILE
+extern "C" int jpeg_amd_debug_phase_cycles(unsigned long long *h_out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_phase_cycles), n * sizeof(unsigned long long));
+}
+extern "C" int jpeg_amd_debug_wave_info(unsigned long long *h_out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_wave_info), n * sizeof(unsigned long long));
+}
+#endif
+
+bool quad_decode_supported(const jpeg_amd_layout &L)
+{
+    if (L.nplanes != 3 || L.precision != 8 || L.scale_x != 2 || L.scale_y != 2) return false;
+    if (L.factor_x[0] != 2 || L.factor_y[0] != 2) return false;
+    for (int p = 1; p < 3; ++p)
+        if (L.factor_x[p] != 1 || L.factor_y[p] != 1) return false;
+    return L.units_x[1] == L.units_x[2] && L.units_y[1] == L.units_y[2];
+}
+
+// Strip shape: 32 x 2 blocks unless 16 x 4 covers the plane with fewer strips (a half-empty strip costs as much as a full
+// one: 1920 x 1080 is 7.5 x 68 strips of 32 x 2 but exactly 15 x 34 of 16 x 4).
+int quad_strip_width(int ux, int uy)
+{
+#ifdef JA_X_FORCE_BX
+    return JA_X_FORCE_BX;
+#endif
+    const long wide = (long)((ux + 31) / 32) * ((uy + 1) / 2), narrow = (long)((ux + 15) / 16) * ((uy + 3) / 4);
+    return narrow < wide ? 16 : 32;
+}
+
+hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const PlaneSet &coef, QuantaRef q,
+                              bool rgb, uint8_t *d_pixels, size_t pixel_stride)
+{
+    QuadArgs a{};
+    for (int p = 0; p < 3; ++p) {
+        a.coef[p] = static_cast<const int16_t *>(coef.ptr[p]);
+        a.coef_stride[p] = coef.stride[p];
+        a.qi[p] = L.qi[p];
+    }
+    a.quanta = q.d_quanta; a.quanta_stride = q.image_stride;
+    a.ux = L.units_x[0]; a.uy = L.units_y[0];
+    a.uxc = L.units_x[1]; a.uyc = L.units_y[1];
+    a.W = L.width; a.H = L.height;
+    a.out = d_pixels; a.out_stride = pixel_stride;
+    const int bx = quad_strip_width(a.ux, a.uy), by = 64 / bx, qs = bx == 32 ? 4 : 2;
+    a.tiles_x = (a.ux + bx - 1) / bx;
+    const int strips_y = (a.uy + by - 1) / by, stacks_y = (strips_y + qs - 1) / qs;
+    a.stacks_per_image = a.tiles_x * stacks_y;
+    const long nstacks = (long)a.stacks_per_image * n_images;
+    if (nstacks == 0) return hipSuccess;
+    if (nstacks > 0x3fffffffL) return hipErrorInvalidValue;
+    a.nstacks = (int)nstacks;
+    const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
+#define JA_Q(BX_)                                                                                                  \
+    {                                                                                                              \
+        if (fast) return rgb ? launch_quad<1, BX_, true>(stream, a) : launch_quad<0, BX_, true>(stream, a);        \
+        return rgb ? launch_quad<1, BX_, false>(stream, a) : launch_quad<0, BX_, false>(stream, a);                \
+    }
+    if (bx == 16) JA_Q(16)
+    JA_Q(32)
+#undef JA_Q
+}
+
+}  // namespace jpeg_amd

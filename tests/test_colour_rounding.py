@@ -106,3 +106,40 @@ def test_encode_matrix_only_the_exact_half_products_may_be_fused():
                     x = fma(mb, b, x) if s3 else x + mb * b
                     same = bool(np.array_equal(np.floor(x), want))
                     assert same == ((s1, s2, s3) in exact_placements[name]), (name, s1, s2, s3)
+
+
+def test_floor_free_chroma_rounding_every_value():
+    """k_luma_fused (4:2:0) rounds the upsampled chroma without a floor (upsample.hpp): bytes enter as 2^15 + p + 1/32,
+    the two 3a + b steps are exact, and ONE fma(., 1/16, C) rounds to the integer.  Every byte pair for the two exact
+    steps, every v = 9a + 3b + 3c + d (0 ... 4080) and both output modes for the rounding."""
+    def fma(a, b, c):   # exact in longdouble for these magnitudes, rounded once to binary32
+        return (a.astype(np.longdouble) * np.longdouble(b) + c.astype(np.longdouble)).astype(f32) if np.ndim(b) == 0 else \
+               (a.astype(np.longdouble) * b.astype(np.longdouble) + c.astype(np.longdouble)).astype(f32)
+
+    byte = np.arange(256, dtype=np.uint32)
+    P = ((np.uint32(0x47000008) | (byte << np.uint32(8))).astype(np.uint32)).view(f32)       # what v_perm_b32 builds
+    assert np.array_equal(P.astype(np.float64), 32768.0 + byte + 1.0 / 32)
+    pn, pf = np.meshgrid(P, P, indexing="ij")
+    bn, bf = np.meshgrid(byte.astype(np.float64), byte.astype(np.float64), indexing="ij")
+    H = fma(pn.ravel(), 3.0, pf.ravel())                                                          # horizontal 3a + b
+    assert np.array_equal(H.astype(np.float64), 131072.0 + (3 * bn + bf).ravel() + 0.125)
+    # vertical 3A + B over every pair of horizontal results would be 1021^2 cases of the same exactness argument; check the
+    # extremes and a dense sample, then every resulting v for the rounding itself
+    h = np.arange(0, 1021, dtype=np.float64)
+    Hs = (131072.0 + h + 0.125).astype(f32)
+    assert np.array_equal(Hs.astype(np.float64), 131072.0 + h + 0.125)
+    hn, hf = np.meshgrid(Hs[::7], Hs[::5], indexing="ij")
+    V = fma(hn.ravel(), 3.0, hf.ravel())
+    vn, vf = np.meshgrid(h[::7], h[::5], indexing="ij")
+    assert np.array_equal(V.astype(np.float64), 524288.0 + (3 * vn + vf).ravel() + 0.5)
+    v = np.arange(0, 4081, dtype=np.float64)
+    Vall = (524288.0 + v + 0.5).astype(f32)
+    assert np.array_equal(Vall.astype(np.float64), 524288.0 + v + 0.5)
+    magic = f32(12582912.0)
+    for sub128 in (True, False):
+        C = f32(12582912.0 - 32768.0 - (128.0 if sub128 else 0.0))
+        t = fma(Vall, f32(1.0 / 16), np.full_like(Vall, C))
+        got = (t - magic).astype(np.float64)
+        want = np.floor((v.astype(f32) * f32(1.0 / 16) + f32(-127.5 if sub128 else 0.5)).astype(f32)).astype(np.float64)  # the staged form
+        assert np.array_equal(got, np.floor(v / 16 + 0.5) - (128 if sub128 else 0))
+        assert np.array_equal(got, want)

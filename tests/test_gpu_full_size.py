@@ -76,10 +76,9 @@ def test_config4_4096x4096_encode(env):
                                     ((2048, 96), 2), ((512, 112), 7), ((3840, 2160), 1), ((256, 32), 9), ((768, 480), 3)],
                          ids=lambda v: str(v))
 def test_quad_shaped_images_match_oracle(env, size, n):
-    """k_luma_fused's QUAD walk (one launch, the four waves of a workgroup share a chroma tile) takes 4:2:0 images made of
-    whole 256-pixel tile columns and whole stacks of four strips (the last strip row may be partial; the last five shapes have a
-    short last stack and take the other paths): one stack high (no neighbour above or below), two, three (both
-    kinds of neighbour), the plane's left and right edge in every row of stacks, batches -- every pixel against the oracle."""
+    """k_quad420's stack walk (one launch, the waves of a workgroup share a chroma tile): images one stack high (no
+    neighbour above or below), two, three (both kinds of neighbour), the plane's left and right edge in every row of stacks,
+    batches, and shapes with a short last stack (the last five) -- every pixel against the oracle."""
     e = env
     planes = e["synth"].natural_planes_torch(e["layout"].units(size), n, e["ctx"].torch_device, 400 + size[1] + n)
     batch = _decode_batch(e, size, planes, n)

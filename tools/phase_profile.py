@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase wall cycles of k_luma_fused's waves (needs a -DJA_PHASE_PROFILE build):
+"""Per-phase wall cycles of k_quad420's waves (one 8192 x 8192 4:2:0 image) (needs a -DJA_PHASE_PROFILE build):
     tools/build_exp.sh prof -DJA_PHASE_PROFILE
     JPEG_AMD_LIBRARY=tools/exp/libjpeg_amd_prof.so python tools/phase_profile.py"""
 import ctypes as C, os, sys
@@ -30,9 +30,9 @@ buf = np.zeros((4096, 16), np.uint64)
 assert fn(buf.ctypes.data, buf.size) == 0
 buf = buf[buf[:, 14] > 0]   # waves that ran (3 072 at three waves per SIMD, 4 096 at four)
 print(f"{len(buf)} waves")
-names = ["wait coef DMA", "QUAD: chroma block read + luma DMA issue", "QUAD: chroma IDCT", "QUAD: wait for the others' reads (WAR)", "QUAD: tile write + arrive",
-         "coef read (+ luma DMA wait / chroma tile DMA issue)", "luma IDCT", "chroma wait + next DMA issue", "hrow prologue + geometry",
-         "pixel rows (QUAD: rows 1-6)", "QUAD: wait for the stack's tile (RAW)", "QUAD: rows 0, 7 (all rows otherwise: see above)"]
+names = ["wait chroma coef DMA", "chroma block read + luma DMA issue", "chroma IDCT + pack", "wait for the others' reads (WAR)",
+         "tile write + arrive", "luma DMA wait + block read + next chroma DMA issue", "luma IDCT", "hrow prologue + geometry",
+         "pixel rows 1-5", "wait for the stack's tile (RAW)", "halo repair, rows 6, 0, 7, last stores", "-"]
 tot = buf[:, :12].sum(axis=1).astype(np.float64)
 print(f"step {ms*1e3:.1f} us; per-wave total cycles mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(names):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One 8192 x 8192 4:2:0 image (config 3) decoded `reps` times from a ring of inputs; prints us per call.
-Development aid for profiler runs: tools/run_c3.py [reps] [W H N]   (JPEG_AMD_BAND=0/1 selects the path)."""
+Development aid for profiler runs: tools/run_c3.py [reps] [W H N]."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -25,4 +25,4 @@ def step(i):
 for i in range(5): step(i)
 torch.cuda.synchronize(); ctx.timer_begin()
 for i in range(reps): step(i)
-print(f"{N} x {W}x{H} RGB: {ctx.timer_end() / reps * 1e3:.1f} us per call (JPEG_AMD_BAND={os.environ.get('JPEG_AMD_BAND', '')})")
+print(f"{N} x {W}x{H} RGB: {ctx.timer_end() / reps * 1e3:.1f} us per call")

@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the C2/C4/C5 side measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
+                    help="roofline.traffic: measured now under rocprofv3 (c3, N = 1), profiles/traffic_latest.json, or null")
     return ap.parse_args()
 
 
@@ -198,14 +200,55 @@ def cpu_baseline(J, quanta_np, seconds, device_case=None, encode_case=None):
     }
 
 
+DECODE_SOURCES = ("kernels_quad.hip", "kernels_fused.hip", "fused_common.hpp", "dct.hpp", "upsample.hpp", "kernels.hpp", "capi.hip")
+
+
 def kernel_source_sha16():
-    """Digest of the device sources of the decode path: `roofline.traffic` (a rocprofv3 PMC measurement kept in
-    profiles/traffic_latest.json) is only reported while it belongs to the kernels that are being timed."""
+    """Digest of the device sources of the decode path: a `roofline.traffic` taken from profiles/traffic_latest.json (the
+    fallback when the live measurement below is unavailable) is only reported while it belongs to the kernels being timed."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels_fused.hip", "dct.hpp", "upsample.hpp", "kernels.hpp"):
+    for f in DECODE_SOURCES:
         h.update(open(os.path.join(ROOT, "jpeg_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def measure_traffic_live(timeout=240):
+    """HBM bytes per launch of the C3 step's kernel, measured NOW on this GPU: two child runs of tools/run_c3.py (the same
+    jpeg_amd_decode_batch call on the same 8192 x 8192 workload) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` -- separate passes, as MI355X_MICROARCH.md's HBM section prescribes; both counters are in KiB and
+    FETCH_SIZE tallies the 128-byte requests of 16-B/lane streaming reads at 64 B on gfx950, so it is doubled.
+    -> (bytes per launch, description) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if os.environ.get("JPEG_AMD_LIBRARY"):
+        return None, "JPEG_AMD_LIBRARY is set: the timed library is not the product build"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="jpeg_amd_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "run_c3.py"), "24"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]!r}"
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if row.get("Counter_Name") == counter and "k_quad420" in row.get("Kernel_Name", "")]
+            if not vals:
+                return None, f"no k_quad420 dispatch in the {counter} pass"
+            out[counter] = (sum(vals) / len(vals), len(vals))
+    except Exception as e:   # never let the measurement break the headline line
+        return None, repr(e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    nbytes = int(round((2.0 * out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0]) * 1024))
+    return nbytes, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/run_c3.py, "
+                    f"mean of {out['FETCH_SIZE'][1]} / {out['WRITE_SIZE'][1]} k_quad420 launches; bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB")
 
 
 def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
@@ -290,15 +333,36 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
         dist.all_gather_object(per_rank, mine)
         assert sum(r["images_per_step"] for r in per_rank) == images_total
 
+    # sustained behaviour (the step runs at the package power limit): ten more windows of 200 steps, not part of `value`
+    sustained = None
+    if world == 1 and workload == "c3" and device_kind == "cuda" and not args.no_extras:
+        win = []
+        for _ in range(10):
+            w_s, _ = time_region(wl, wl.step, 200, sync, barrier)
+            win.append(w_s / 200 * 1e3)
+        win.sort()
+        sustained = {"steps": 2000, "windows": 10, "ms_per_step_min": round(win[0], 5), "ms_per_step_median": round((win[4] + win[5]) / 2, 5),
+                     "ms_per_step_max": round(win[-1], 5),
+                     "frac_hbm_median": round(wl.bytes / ((win[4] + win[5]) / 2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "frac_hbm_min_max": [round(wl.bytes / (win[-1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), round(wl.bytes / (win[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)],
+                     "note": "2000 further steps right after the timed region, wall clock per window of 200"}
+
     result = None
     if rank == 0:
         pixels_per_step = wl.pixels_per_image * images_total
         value = pixels_per_step * args.steps / wall_max / 1e6
         gpu_s_per_step = gpu_ms / 1e3 / args.steps
-        achieved = wl.bytes / gpu_s_per_step / 1e9
+        # `achieved` / `frac` follow from the same clock as `value` (wall time between the barriers, launch gaps included);
+        # the HIP-event time of rank 0's stream is the named secondary
+        achieved = wl.bytes / (wall_max / args.steps) / 1e9
+        achieved_events = wl.bytes / gpu_s_per_step / 1e9
         traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and device_kind == "cuda":
+        mode = getattr(args, "traffic", "live")
+        if mode == "live" and workload == "c3" and world == 1 and device_kind == "cuda":
+            traffic, traffic_note = measure_traffic_live()
+        if traffic is None and mode != "none" and os.path.exists(tpath) and device_kind == "cuda":
+            live_note = traffic_note
             try:
                 tj = json.load(open(tpath))
                 per_step = tj.get("hbm_bytes_per_step") if workload == "c3" else None
@@ -314,6 +378,8 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
                     traffic_note = f"rocprofv3 PMC passes of this workload at commit {tj.get('commit')} (tools/profile_round.sh)"
             except Exception as e:
                 traffic_note = repr(e)
+            if live_note:
+                traffic_note = f"{traffic_note}; live measurement unavailable: {live_note}"
         result = {
             "metric": "Mpixels/s decode (IDCT+dequant+upsample+YCbCr->RGB); % HBM roofline",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world,
@@ -329,7 +395,10 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_note,
                          "algorithmic_bytes_per_step": wl.bytes,
+                         "clock": "wall time of the timed region / steps (the clock of `value`)",
                          "gpu_ms_per_step_hip_events": round(gpu_s_per_step * 1e3, 5),
+                         "achieved_hip_events": round(achieved_events, 1),
+                         "frac_hip_events": round(achieved_events / HBM_PEAK_GBS, 4),
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
                          "kernels": "all kernels of one fused decode step (rank 0's shard)"},
         }
@@ -339,6 +408,8 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
         encode_case = None
         if world == 1 and not args.no_extras:
             result["extra"] = extras(J, ctx, d_quanta, q_np, sync, args, workload)
+            if sustained:
+                result["extra"]["c3_sustained"] = sustained
             encode_case = result["extra"].pop("_c4_host_case", None)
             # what the vendor's device-to-device memcpy moves on THIS box (read + written bytes per
             # second), measured just now: the practical ceiling of a 1 : 1 read / write stream
@@ -349,7 +420,7 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
                 rf["achieved_over_d2d_memcpy"] = round(rf["achieved"] / d2d, 4)
                 if rf["traffic"]:
                     rf["traffic_rate_over_d2d_memcpy"] = round(
-                        rf["traffic"] / (rf["gpu_ms_per_step_hip_events"] * 1e-3) / 1e9 / d2d, 4)
+                        rf["traffic"] / (result["ms_per_step"] * 1e-3) / 1e9 / d2d, 4)
         if world == 1 and not args.no_cpu:
             planes_h, pixels_h = wl.host_case(0)
             cb = cpu_baseline(J, q_np, args.cpu_seconds, (planes_h, pixels_h, wl.size), encode_case)

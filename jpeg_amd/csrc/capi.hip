@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -909,26 +910,37 @@ try {
         // the device side of chunk k (asynchronous); the host moves on to chunk k + 1 meanwhile.
         // Device slot `slot` was last read by the download of chunk k - 2, finished before drain(k - 2)
         // returned.  Upload + kernels on the context's stream, download on the second one.
-        char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
-        const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
-        for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<const int16_t *>(dev + coef_off[c]);
-        size_t stride[JPEG_AMD_MAX_PLANES] = {};
-        for (int c = 0; c < nc; ++c) {
-            stride[c] = plane[c];
-            JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c], host + coef_off[c], plane[c] * 2 * m, hipMemcpyHostToDevice, ctx->stream));
-        }
-        JA_HIP(ctx, hipMemcpyAsync(dev + quanta_off, host + quanta_off, (size_t)m * kQSlotElems * 2, hipMemcpyHostToDevice, ctx->stream));
-        JA_TRY(jpeg_amd_decode_batch(ctx, &L, m, d_coef, stride, reinterpret_cast<const uint16_t *>(dev + quanta_off), kQSlotElems,
-                                     JPEG_AMD_MAX_PLANES, cosited, color, reinterpret_cast<uint8_t *>(dev + px_off), npx));
-        JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
-        JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
-        JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
-        JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->file_d2h));
+        // (a failure in here leaves copies and kernels in flight: no early return, the common tail below waits for both streams)
+        auto submit = [&]() -> int {
+            char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
+            const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+            for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<const int16_t *>(dev + coef_off[c]);
+            size_t stride[JPEG_AMD_MAX_PLANES] = {};
+            for (int c = 0; c < nc; ++c) {
+                stride[c] = plane[c];
+                JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c], host + coef_off[c], plane[c] * 2 * m, hipMemcpyHostToDevice, ctx->stream));
+            }
+            JA_HIP(ctx, hipMemcpyAsync(dev + quanta_off, host + quanta_off, (size_t)m * kQSlotElems * 2, hipMemcpyHostToDevice, ctx->stream));
+            JA_TRY(jpeg_amd_decode_batch(ctx, &L, m, d_coef, stride, reinterpret_cast<const uint16_t *>(dev + quanta_off), kQSlotElems,
+                                         JPEG_AMD_MAX_PLANES, cosited, color, reinterpret_cast<uint8_t *>(dev + px_off), npx));
+            JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
+            JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
+            JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
+            JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->file_d2h));
+            return JPEG_AMD_OK;
+        };
+        result = submit();
+        if (result != JPEG_AMD_OK) break;
         // chunk k - 1 is copied out by a helper thread WHILE the host decodes chunk k + 1; it has
         // to be finished before chunk k + 1 is submitted (its download lands in the same pinned slot)
         if (k >= 1) {
             drain_status = JPEG_AMD_OK;
-            drainer = std::thread([&, k] { (void)hipSetDevice(ctx->device); drain_status = drain(k - 1); });
+            try {
+                drainer = std::thread([&, k] { (void)hipSetDevice(ctx->device); drain_status = drain(k - 1); });
+            } catch (const std::system_error &) {
+                drain_status = drain(k - 1);   // no helper thread to be had: copy the chunk out here
+                if (drain_status != JPEG_AMD_OK) { result = drain_status; break; }
+            }
         }
     }
     if (drainer.joinable()) drainer.join();

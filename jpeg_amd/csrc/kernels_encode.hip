@@ -516,7 +516,9 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     const int tiles_y = (need_y + ty - 1) / ty;
     if (a.tiles_x * tiles_y == 0 || n_images == 0) return hipSuccess;
     const dim3 grid(a.tiles_x * tiles_y, n_images);
-    const bool fast = (L.width & 7) == 0 && (pixel_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 7) == 0;
+    // (the vector-load path addresses a tile's rows with 32-bit byte offsets: 16 block rows x 8 x W x 3 B must stay below 2^32)
+    const bool fast = (L.width & 7) == 0 && (pixel_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 7) == 0 &&
+                      L.width <= (1 << 23);
 #define JA_E(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_>), grid, dim3(kThreads), 0, stream, a)
 #define JA_E8(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_, 8>), grid, dim3(kThreads), 0, stream, a)
 #define JA_E2(RGB_, F_)                                         \

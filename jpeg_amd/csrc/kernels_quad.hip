@@ -138,73 +138,64 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
     // of block b = u >> 3 -- the XOR on the SOURCE address makes the later per-work-item ds_read_b128 (stride 128 B)
     // bank-conflict-free.  Where the eight blocks of an instruction are neighbours in a block row, the block index is
     // scalar and only the lane's place inside the group is per lane (`ve`; odd i: chunk ^ 4).
-    auto dma_chroma = [&](int q, int lane) {
-        int img, syi, sxi;
-        locate(q, img, syi, sxi);
+    // `i`: the instruction (0 .. NDMA_C - 1 / 0 .. 7); the strip walks issue them one at a time between the columns of a
+    // transform (idct_block_hooked), the prologue all at once.
+    auto dma_chroma_one = [&](int i, int img, int syi, int sxi, int lane) {
         const uint32_t l3 = lane >> 3;
-        const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
-        int first_general = 0;
-        if (CBW * sxi + CBW <= a.uxc) {   // wave-uniform: the strip's chroma columns lie inside the plane
+        if (i < 6 && CBW * sxi + CBW <= a.uxc) {   // wave-uniform: the strip's chroma columns lie inside the plane
+            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
             const int top = syi - qp;
             const int halo_row = min(max(qp < QS / 2 ? CBR * top - 1 : CBR * (top + QS), 0), a.uyc - 1);   // missing rows: fetched, not used
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                int pl, row, col0;
-                if constexpr (BX == 32) { pl = i < 4 ? i >> 1 : (qp & 1); row = i < 4 ? syi : halo_row; col0 = 16 * sxi + 8 * (i & 1); }
-                else { pl = i < 4 ? i >> 1 : (i & 1); row = i < 4 ? 2 * syi + (i & 1) : halo_row; col0 = 8 * sxi; }
-                row = min(row, a.uyc - 1);
-                const uint64_t sb = reinterpret_cast<uint64_t>(a.coef[1 + pl] + img * a.coef_stride[1 + pl]) +
-                                    ((uint64_t)((uint32_t)row * (uint32_t)a.uxc + (uint32_t)col0) << 7);
-                lds_dma16_s_keep(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
-            }
-            first_general = 6;
-        }
-#pragma unroll
-        for (int i = 0; i < NDMA_C; ++i) {
-            if (i < first_general) continue;
-            const int b = 8 * i + (lane >> 3);
-            int pl, bx, by;
-            if (BX == 32 && i == 6) {   // sides (48..51) and corners (52..55): the same map as quad_block with fewer branches
-                const int top = syi - qp;
-                pl = (b >> 1) & 1; bx = (b & 1) ? 16 * sxi + 16 : 16 * sxi - 1; by = b < 52 ? syi : (qp < 2 ? top - 1 : top + QS);
-            } else {
-                quad_block(b, syi, sxi, pl, bx, by);
-            }
-            by = min(max(by, 0), a.uyc - 1);   // missing rows: fetched, not used
-            const int16_t *cbase = a.coef[1 + pl] + img * a.coef_stride[1 + pl];
-            const uint32_t blk = (bx >= 0 && bx < a.uxc) ? (uint32_t)by * a.uxc + bx : 0u;
-            const int c = (lane & 7) ^ ((b >> 1) & 7);
-            lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
-        }
-    };
-    auto dma_luma = [&](int img, int syi, int sxi, int lane) {
-        const int16_t *base = a.coef[0] + img * a.coef_stride[0];
-        if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {   // interior strip (wave-uniform)
-            const uint32_t l3 = lane >> 3;
-            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t blk0 = (uint32_t)(BY * syi + i / (BX / 8)) * a.ux + sxi * BX + 8 * (i % (BX / 8));
-                const uint64_t sb = reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7);
-                lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
-            }
+            int pl, row, col0;
+            if constexpr (BX == 32) { pl = i < 4 ? i >> 1 : (qp & 1); row = i < 4 ? syi : halo_row; col0 = 16 * sxi + 8 * (i & 1); }
+            else { pl = i < 4 ? i >> 1 : (i & 1); row = i < 4 ? 2 * syi + (i & 1) : halo_row; col0 = 8 * sxi; }
+            row = min(row, a.uyc - 1);
+            const uint64_t sb = reinterpret_cast<uint64_t>(a.coef[1 + pl] + img * a.coef_stride[1 + pl]) +
+                                ((uint64_t)((uint32_t)row * (uint32_t)a.uxc + (uint32_t)col0) << 7);
+            lds_dma16_s_keep(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
             return;
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int b = 8 * i + (lane >> 3);  // block within the strip: column b % BX, row b / BX
-            const int bx = sxi * BX + (b & (BX - 1)), by = BY * syi + (int)((unsigned)b / BX);
-            // blocks outside the plane fetch block 0; the store predicate discards their pixels
-            const uint32_t blk = (bx < a.ux && by < a.uy) ? (uint32_t)by * a.ux + bx : 0u;
-            const int c = (lane & 7) ^ ((b >> 1) & 7);
-            lds_dma16(reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+        const int b = 8 * i + (int)l3;
+        int pl, bx, by;
+        if (BX == 32 && i == 6) {   // sides (48..51) and corners (52..55): the same map as quad_block with fewer branches
+            const int top = syi - qp;
+            pl = (b >> 1) & 1; bx = (b & 1) ? 16 * sxi + 16 : 16 * sxi - 1; by = b < 52 ? syi : (qp < 2 ? top - 1 : top + QS);
+        } else {
+            quad_block(b, syi, sxi, pl, bx, by);
         }
+        by = min(max(by, 0), a.uyc - 1);   // missing rows: fetched, not used
+        const int16_t *cbase = a.coef[1 + pl] + img * a.coef_stride[1 + pl];
+        const uint32_t blk = (bx >= 0 && bx < a.uxc) ? (uint32_t)by * a.uxc + bx : 0u;
+        const int c = (lane & 7) ^ ((b >> 1) & 7);
+        lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+    };
+    auto dma_luma_one = [&](int i, int img, int syi, int sxi, int lane) {
+        const int16_t *base = a.coef[0] + img * a.coef_stride[0];
+        const uint32_t l3 = lane >> 3;
+        if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {   // interior strip (wave-uniform)
+            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+            const uint32_t blk0 = (uint32_t)(BY * syi + i / (BX / 8)) * a.ux + sxi * BX + 8 * (i % (BX / 8));
+            const uint64_t sb = reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7);
+            lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+            return;
+        }
+        const int b = 8 * i + (int)l3;  // block within the strip: column b % BX, row b / BX
+        const int bx = sxi * BX + (b & (BX - 1)), by = BY * syi + (int)((unsigned)b / BX);
+        // blocks outside the plane fetch block 0; the store predicate discards their pixels
+        const uint32_t blk = (bx < a.ux && by < a.uy) ? (uint32_t)by * a.ux + bx : 0u;
+        const int c = (lane & 7) ^ ((b >> 1) & 7);
+        lds_dma16(reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
     };
 
 #ifdef JA_X_STAGGER   // experiment: the three workgroups of a CU start a third of a strip apart
     for (int d = (int)(blockIdx.x / 256u) * (JA_X_STAGGER); d > 0; d -= 64 * 100) __builtin_amdgcn_s_sleep(100);
 #endif
-    dma_chroma(stack_of(0), lane0);
+    {
+        int img, syi, sxi;
+        locate(stack_of(0), img, syi, sxi);
+#pragma unroll
+        for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, img, syi, sxi, lane0);
+    }
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
     JA_PHASE_DECL
@@ -231,6 +222,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         //      order and the DMA was issued BEFORE the previous strip's pixel stores: when that strip took the branch-free
         //      store path (exactly 2 store instructions per pixel row) only the DMA has to be waited for ----
         if (stores_behind_dma == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (stores_behind_dma == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (stores_behind_dma == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (stores_behind_dma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (stores_behind_dma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         JA_PHASE(0)
         // The scheduler of a SIMD issues its oldest ready wave first.  From the start of a strip to the arrival at the
@@ -251,7 +246,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         const uint32_t done_seen = lds_peek(done);   // checked after the transform; read here so that the check costs no round trip
         // w holds the chroma pass's block; the luma blocks of the strip follow it into the buffer
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_luma(img, syi, sxi, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma_luma_one(i, img, syi, sxi, lane);
+        __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(1)
 
         const int top = syi - qp;
@@ -335,11 +332,46 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        JA_PHASE(11)
         read_block();
         // ---- the coefficient buffer is consumed: prefetch the next stack's chroma pass into it.  From here to the end of
-        //      the strip only stores are issued, so nothing waits on the DMA. ----
+        //      the strip only stores are issued, so nothing waits on the DMA.  (One DMA instruction in front of each column of
+        //      the transform instead of eight in a row, pinned with scheduling barriers, costs the transform more than the
+        //      burst costs: a column alone has too little instruction-level parallelism -- 88 against 86 us.) ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (trip + 1 < trips) dma_chroma(stack_of(trip + 1), lane);
+        JA_PHASE(12)
+        const bool more = trip + 1 < trips;
+        int n_img = 0, n_syi = 0, n_sxi = 0;
+        if (more) locate(stack_of(trip + 1), n_img, n_syi, n_sxi);
+#ifdef JA_X_PACED   // experiment: the prefetch issued two instructions at a time in front of the first pixel rows
+        constexpr int kPace = JA_X_PACED;
+#else
+        constexpr int kPace = 0;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, n_img, n_syi, n_sxi, lane);
+        }
+#endif
+        auto pace = [&](int idx) {
+            if constexpr (kPace > 0) {
+#pragma unroll
+                for (int i = kPace * idx; i < kPace * idx + kPace; ++i)
+                    if (i < NDMA_C && more) dma_chroma_one(i, n_img, n_syi, n_sxi, lane);
+            }
+        };
+        constexpr int kPaceSteps = kPace > 0 ? (NDMA_C + kPace - 1) / kPace : 0;        // steps that issue DMA instructions
+        constexpr int kStoresBehind = kPace > 0 ? 2 * (8 - (kPaceSteps - 1) + 1) : 16;     // store instructions behind the last one
+        __builtin_amdgcn_sched_barrier(0);
+        JA_PHASE(13)
+        // the chroma dwords of the first three patch rows the pixel rows need (the wave's own samples): requested here, they
+        // land during the transform
+        uint32_t raw1[2][3], raw2[2][3], rawn[2][3], raw0[2][3];
+        auto hraw = [&](int pl, int j, uint32_t (&r)[3]) {
+            const uint32_t *row = sc + pl * PLANE + (seg * 4 + j) * PITCH;
+            r[0] = row[lbx]; r[1] = row[1 + lbx]; r[2] = row[2 + lbx];
+        };
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) { hraw(pl, 1, raw1[pl]); hraw(pl, 2, raw2[pl]); hraw(pl, 3, rawn[pl]); }
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(5)
 
@@ -362,10 +394,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         // ---- chroma rows, produced just in time from the tile.  Patch row j of a block: window row seg (8 / 2) + j;
         //      the LDS reads (hraw) and the conversion + horizontal interpolation (hconv) are separate so that the reads
         //      can be issued well ahead of their use ----
-        auto hraw = [&](int pl, int j, uint32_t (&r)[3]) {
-            const uint32_t *row = sc + pl * PLANE + (seg * 4 + j) * PITCH;
-            r[0] = row[lbx]; r[1] = row[1 + lbx]; r[2] = row[2 + lbx];
-        };
         auto hconv = [&](const uint32_t (&r)[3], float (&o)[8]) {   // samples enter as 2^15 + p + 1/32 (upsample.hpp)
             const float p[6] = {ubyte_magic<3>(r[0]), ubyte_magic<0>(r[1]), ubyte_magic<1>(r[1]),
                                 ubyte_magic<2>(r[1]), ubyte_magic<3>(r[1]), ubyte_magic<0>(r[2])};
@@ -377,13 +405,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         };
         // slot 0 = patch row 1 (kept for pixel row 0), slots 1 / 2 the sliding pair
         float hw[2][3][8];
-        uint32_t rawn[2][3], raw0[2][3];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            uint32_t r1[3], r2[3];
-            hraw(pl, 1, r1); hraw(pl, 2, r2); hraw(pl, 3, rawn[pl]);
-            hconv(r1, hw[pl][0]); hconv(r2, hw[pl][1]);
-        }
+        for (int pl = 0; pl < 2; ++pl) { hconv(raw1[pl], hw[pl][0]); hconv(raw2[pl], hw[pl][1]); }
 
         // ---- store geometry: per pixel row the strip's BY segments are 96 chunks of 16 B; a lane stores chunk `lane` (and
         //      lanes 0..31 also chunk 64 + lane).  Both store instructions of a row cover whole 128-byte lines. ----
@@ -398,7 +421,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = sg1 * 8u * pitch + 16u * j1;
         const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
-        stores_behind_dma = (FAST && full) ? 16 : 0;
+        stores_behind_dma = (FAST && full) ? kStoresBehind : 0;
         JA_PHASE(7)
 
         // One pixel row of the strip's BY block rows at a time, software-pipelined: row y is staged (ds_write) and read
@@ -429,7 +452,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         };
         // pixel row y of the work-item's block: vertical interpolation (the nearer patch row weighs 3), colour, pack; then the
         // row's traffic: the previous row's stores, this row's staging
-        auto step = [&](int y, int near, int far, int prev) __attribute__((always_inline)) {
+        auto step = [&](int idx, int y, int near, int far, int prev) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            pace(idx);
             __builtin_amdgcn_sched_barrier(0);
             float cv[2][8];
 #pragma unroll
@@ -470,18 +495,18 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         };
         // Rows in the order 1 2 3 4 5 6 | 0 7: only row 0 of the strip's first block row reads the sample row above the wave's
         // own (patch row 0) and only row 7 of its last block row the one below (patch row 5) -- samples other waves produce.
-        step(1, 0, 1, -1);                                    // patch rows 1 (near), 2
-        step(2, 1, 0, 1);                                     // 2, 1
+        step(0, 1, 0, 1, -1);                                    // patch rows 1 (near), 2
+        step(1, 2, 1, 0, 1);                                     // 2, 1
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][2]);   // patch row 3
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) hraw(pl, 4, rawn[pl]);
-        step(3, 1, 2, 2);                                     // 2, 3
-        step(4, 2, 1, 3);                                     // 3, 2
+        step(2, 3, 1, 2, 2);                                     // 2, 3
+        step(3, 4, 2, 1, 3);                                     // 3, 2
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][1]);   // patch row 4 (row 2 is dead)
         const uint32_t ready_seen = lds_peek(ready);
-        step(5, 2, 1, 4);                                     // 3, 4
+        step(4, 5, 2, 1, 4);                                     // 3, 4
         JA_PHASE(8)
         // ---- the stack's tile is complete: everyone's samples of this trip are in it ----
         lds_wait_ge_seen(ready, (uint32_t)(QS * (trip + 1)), ready_seen);
@@ -506,13 +531,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         for (int pl = 0; pl < 2; ++pl) { hraw(pl, 0, raw0[pl]); hraw(pl, 5, rawn[pl]); }
         // those were this trip's last reads of samples another wave wrote (the LDS performs them before the add)
         lds_arrive(done, lane);
-        step(6, 1, 2, 5);                                     // 4, 3
+        step(5, 6, 1, 2, 5);                                     // 4, 3
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) hconv(raw0[pl], hw[pl][2]);   // patch row 0 (row 3 is dead)
-        step(0, 0, 2, 6);                                     // 1, 0
+        step(6, 0, 0, 2, 6);                                     // 1, 0
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][2]);   // patch row 5
-        step(7, 1, 2, 0);                                     // 4, 5
+        step(7, 7, 1, 2, 0);                                     // 4, 5
         __builtin_amdgcn_sched_barrier(0);
         store_row(7);
         JA_PHASE(10)

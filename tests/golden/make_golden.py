@@ -196,6 +196,23 @@ def main():
         written.append({"file": "encode/" + fn, "origin": origin, "file_sha256": sha_file(os.path.join(REF, origin)),
                         "file_nbytes": os.path.getsize(os.path.join(REF, origin))})
     manifest["encode"]["written_by_reference"] = written
+    # examples/custom-color/main.swift:132-200 compresses a deterministic 1000 x 200 RGBA12 gradient (alpha 0x0fff) into
+    # output.jpg (12-bit, 4 components, factors (2,2) x 3 + (1,1), 16-bit tables) and dumps that INPUT as output.jpg.rgb
+    # (two bytes per channel: high 8 bits, low 4 bits << 4): together they pin pack + decomposed + fdct at precision 12
+    # -- the coefficients inside the file are what the reference computed from the dump.  1.2 MB of smooth gradient: kept
+    # xz-compressed (3.4 KB), digest of the raw dump recorded.
+    import lzma
+    dump = open(os.path.join(REF, "examples/custom-color/output.jpg.rgb"), "rb").read()
+    with open(os.path.join(HERE, "encode", "custom-color-output.jpg.rgb.xz"), "wb") as f:
+        f.write(lzma.compress(dump, preset=9))
+    cc = R.read_jpeg(os.path.join(REF, "examples/custom-color/output.jpg"))
+    manifest["custom_color"] = {
+        "file": "encode/custom-color-output.jpg", "source": "encode/custom-color-output.jpg.rgb.xz",
+        "origin": "examples/custom-color/output.jpg.rgb", "source_sha256": hashlib.sha256(dump).hexdigest(),
+        "source_nbytes": len(dump), "size": [cc.width, cc.height], "precision": cc.precision, "alpha": 0x0fff,
+        "factors": [[c.fx, c.fy] for c in cc.components], "idents": [c.ident for c in cc.components],
+        "quanta": [[int(v) for v in cc.quanta[i]] for i in range(len(cc.planes))],
+        "coef_sha256": [sha(p) for p in cc.planes]}
     # examples/in-memory also dumps the decoded picture; the re-compressed file above holds the
     # same coefficients as the original, so it pins the decode of a progressive 4:4:4 file
     manifest["in_memory"] = {"file": "encode/karlie-2011.jpg.jpg", "origin": "examples/in-memory/karlie-2011.jpg.rgb",

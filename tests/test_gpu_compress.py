@@ -128,3 +128,26 @@ def test_compress_batch_writes_the_references_file_for_every_image(ctx):
     st = _lib.lib().jpeg_amd_compress_batch(ctx.handle, C.byref(info), px.ctypes.data, 0, n, J.RGB.code, qkey, tables.ctypes.data,
                                             tk, 2, sarr, 2, marr, nmeta, 3, out.ctypes.data, 1000, sizes)
     assert st == _lib.EINVAL and sizes[0] == case["file_nbytes"]
+
+
+def test_twelve_bit_four_component_compress_reproduces_the_references_file(ctx):
+    """examples/custom-color/output.jpg from the gradient the reference made it from (tests/golden/make_golden.py keeps
+    the reference's dump of that input): Rectangular.decomposed() -> Planar.fdct(quanta:) on the device at precision 12
+    == the coefficient planes inside the file, and compress(...) with the example's scan progression (main.swift:101-118)
+    == the file, byte for byte.  (The CPU twin, oracle against the same file: tests/test_oracle_golden.py.)"""
+    import jpeg_amd as J
+    from oracle import jpeg_reader
+    from test_entropy_encode_cpu import _script
+    values, size, factors, quanta, file, m = G.custom_color()
+    data = np.fromfile(file, np.uint8)
+    process, metadata, scans, keys, tkeys, tables = _script(data)
+    assert process == 2 and keys == [0, 0, 0, 1]
+    layout = J.Layout(("custom", 12, 4), {i: J.Component(f, k) for i, f, k in zip(m["idents"], factors, keys)})
+    rect = J.Rectangular.from_host(ctx, size, layout, values)
+    qd = {k: tables[tkeys.index(k)] for k in tkeys}
+    spectral = rect.decomposed().fdct(qd)
+    want = jpeg_reader.read_jpeg(file).planes
+    for got, w in zip(spectral.host_planes(), want):
+        assert got.shape == w.shape and (got == w).all()
+    out = rect.compress(qd, scans, process="progressive", metadata=metadata)
+    assert bytes(out) == data.tobytes()

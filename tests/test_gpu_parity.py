@@ -344,12 +344,15 @@ def test_fused_kernels_on_random_geometry(J, ctx, case):
         assert (a == b).all(), "encode differs"
 
 
-# ---- f-4: generic JPEG.Format plug-ins -- parity-unpinned: the reference holds no gold for 12 / 16-bit,
-# ---- 4-plane or cosited data (examples/custom-color only writes a JPEG), so the oracle is the only checker here -----
+# ---- f-4: generic JPEG.Format plug-ins.  The ENCODE half at precision 12 / four planes is pinned on a
+# ---- reference-held vector: examples/custom-color's output.jpg + the dump of its input (tests/test_oracle_golden.py::
+# ---- test_twelve_bit_four_component_encode_pin for the oracle, tests/test_gpu_compress.py::test_twelve_bit_... for the
+# ---- device).  The DECODE half (12 / 16-bit idct, cosited and odd-factor upsampling) has no gold in the reference: there
+# ---- the oracle is the only checker -- the tests below say so in their names ------------------------------------------
 
 @pytest.mark.parametrize("precision", [12, 16])
 @pytest.mark.parametrize("nplanes", [1, 3, 4])
-def test_generic_format_decode_and_encode_parity_unpinned_no_reference_gold(J, ctx, precision, nplanes):
+def test_generic_format_decode_unpinned_no_reference_gold_and_encode_beyond_the_pinned_case(J, ctx, precision, nplanes):
     """Spectral.idct / Planar.interleaved (centred and cosited) and Rectangular.decomposed / Planar.fdct for custom
     formats of 12 and 16 bits: decode.swift:4101-4133 with level 2^(P-1) + 0.5 and clamp to 2^P - 1, and
     encode.swift:80-99 where load() clamps samples ABOVE the format's limit (min(limit, sample)) -- the samples fed
@@ -398,7 +401,7 @@ def test_generic_format_decode_and_encode_parity_unpinned_no_reference_gold(J, c
 
 
 @pytest.mark.parametrize("seed", range(4))
-def test_generic_format_seeded_sweep_parity_unpinned_no_reference_gold(J, ctx, seed):
+def test_generic_format_seeded_sweep_decode_unpinned_no_reference_gold(J, ctx, seed):
     """Ten random formats per seed (1-4 planes, factors 1-4, 8 / 12 / 16 bits, centred or cosited) through the staged
     kernels both ways -- the collected share of tests/soak_staged.py."""
     rng = np.random.default_rng(9000 + seed)

@@ -77,3 +77,21 @@ def test_encode_golds_against_files(case):
     planes = O.encode(rgb, size, [tuple(f) for f in case["factors"]], img.quanta)
     for a, b in zip(planes, img.planes):
         assert (a == b).all()
+
+
+def test_twelve_bit_four_component_encode_pin():
+    """examples/custom-color (main.swift:132-200): the reference compressed a deterministic RGBA12 gradient into
+    output.jpg -- 12-bit, four components, factors (2,2) x 3 + (1,1), 16-bit tables -- and dumped that input beside it.
+    decomposed() (a (1,1) plane inside a (2,2) scale: 2 x 2 box filter, encode.swift:389-425) + load(limit:) + fdct at
+    P = 12 (encode.swift:80-99, 199-248) on the dump == the coefficients inside the file: the pin SURVEY 8c thought
+    missing for precision 12."""
+    from oracle import jpeg_reader
+    values, size, factors, quanta, file, m = G.custom_color()
+    img = jpeg_reader.read_jpeg(file)
+    assert (img.precision, len(img.planes)) == (12, 4) and m["precision"] == 12
+    assert [q.tolist() for q in quanta] == [img.quanta[i].tolist() for i in range(4)]
+    planes = O.decompose(values, size, factors, (2, 2))
+    for p, q, want, digest in zip(planes, quanta, img.planes, m["coef_sha256"]):
+        got = O.fdct_plane(p, q, 12)
+        assert got.shape == want.shape and (got == want).all()
+        assert G.sha(got) == digest

@@ -31,9 +31,10 @@ assert fn(buf.ctypes.data, buf.size) == 0
 buf = buf[buf[:, 14] > 0]   # waves that ran (3 072 at three waves per SIMD, 4 096 at four)
 print(f"{len(buf)} waves")
 names = ["wait chroma coef DMA", "chroma block read + luma DMA issue", "chroma IDCT + pack", "wait for the others' reads (WAR)",
-         "tile write + arrive", "luma DMA wait + block read + next chroma DMA issue", "luma IDCT", "hrow prologue + geometry",
-         "pixel rows 1-5", "wait for the stack's tile (RAW)", "halo repair, rows 6, 0, 7, last stores", "-"]
-tot = buf[:, :12].sum(axis=1).astype(np.float64)
+         "tile write + arrive", "patch row requests", "luma IDCT", "hrow prologue + geometry",
+         "pixel rows 1-5", "wait for the stack's tile (RAW)", "halo repair, rows 6, 0, 7, last stores", "luma DMA wait (vmcnt 0)",
+         "luma block read + lgkmcnt(0)", "next chroma DMA issue"]
+tot = buf[:, :14].sum(axis=1).astype(np.float64)
 print(f"step {ms*1e3:.1f} us; per-wave total cycles mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(names):
     c = buf[:, i].astype(np.float64)

@@ -12,6 +12,9 @@
 //   Planar.interleaved(cosite:)                           decode.swift:4181-4276
 //   Planar.fdct(quanta:)                                  encode.swift:352-370
 //   Rectangular.decomposed()                              encode.swift:388-425
+//   additions (no counterpart in the reference: the three decode stages in one PCIe round trip)
+//   Spectral.decode(as:cosite:)  for JPEG.RGB / JPEG.YCbCr  = idct().interleaved(cosite:).unpack(as:)
+//   AMD.withDevice(_:_:) / AMD.device / AMD.deviceCount      which GPU a thread's calls run on
 //   overloads (the reference's generic definition stays for every other JPEG.Color conformance)
 //   Rectangular.unpack(as:)  for JPEG.RGB / JPEG.YCbCr    decode.swift:4291-4298
 //   Rectangular.pack(size:layout:metadata:pixels:)  same  encode.swift:453-464
@@ -32,29 +35,82 @@ enum AMD
     /// A jpeg_amd_ctx is single-threaded (include/jpeg_amd.h), while the methods replaced here are pure functions of
     /// value types that callers may run on several threads at once: contexts are borrowed from a pool for the
     /// duration of one call (created on demand, returned afterwards), never shared between two running calls.
+    ///
+    /// One pool PER DEVICE.  Which device a call runs on: `AMD.device` of the calling thread if it has been set
+    /// (`AMD.withDevice(3) { ... }`: a host that shards a batch of images over the node's GPUs runs one thread -- or one
+    /// `DispatchQueue.concurrentPerform` iteration -- per shard inside such a scope), otherwise round-robin over
+    /// `jpeg_amd_device_count` devices.  The images of the path are independent (SURVEY.md 8e): there is no data-path
+    /// exchange between devices, so nothing else has to be coordinated.
     private final
     class Pool
     {
         var lock:pthread_mutex_t = .init()
-        var free:[OpaquePointer] = []
-        init() { pthread_mutex_init(&self.lock, nil) }
+        var free:[[OpaquePointer]] = []     // per device
+        var next:Int = 0                    // round-robin cursor
+        init()
+        {
+            pthread_mutex_init(&self.lock, nil)
+            var n:Int32 = 0
+            let status:Int32 = jpeg_amd_device_count(&n)
+            precondition(status == 0 && n > 0, "jpeg_amd_device_count: no MI355X visible")
+            self.free = .init(repeating: [], count: .init(n))
+        }
     }
     private static let pool:Pool = .init()
+    /// Number of GPUs the library sees.
+    static var deviceCount:Int { Self.pool.free.count }
+
+    // the calling thread's device choice: a pthread key, so that it works on any thread the host creates
+    private static let deviceKey:pthread_key_t =
+    {
+        var key:pthread_key_t = .init()
+        pthread_key_create(&key, nil)
+        return key
+    }()
+    /// The device of the calling thread's calls: nil = round-robin.
+    static var device:Int?
+    {
+        get
+        {
+            guard let raw:UnsafeMutableRawPointer = pthread_getspecific(Self.deviceKey) else { return nil }
+            return Int(bitPattern: raw) - 1
+        }
+        set
+        {
+            pthread_setspecific(Self.deviceKey, newValue.map{ UnsafeMutableRawPointer(bitPattern: $0 + 1) } ?? nil)
+        }
+    }
+    /// Runs `body` with every hot-path call of this thread on `device`.
+    static func withDevice<R>(_ device:Int, _ body:() throws -> R) rethrows -> R
+    {
+        precondition(0 <= device && device < Self.deviceCount, "device \(device) of \(Self.deviceCount)")
+        let outer:Int? = Self.device
+        Self.device = device
+        defer { Self.device = outer }
+        return try body()
+    }
 
     static func withContext<R>(_ body:(OpaquePointer) -> R) -> R
     {
         pthread_mutex_lock(&Self.pool.lock)
-        var ctx:OpaquePointer? = Self.pool.free.popLast()
+        let device:Int
+        if let chosen:Int = Self.device { device = chosen }
+        else
+        {
+            device = Self.pool.next
+            Self.pool.next = (Self.pool.next + 1) % Self.pool.free.count
+        }
+        var ctx:OpaquePointer? = Self.pool.free[device].popLast()
         pthread_mutex_unlock(&Self.pool.lock)
         if ctx == nil
         {
-            let status:Int32 = jpeg_amd_ctx_create(0, nil, JPEG_AMD_CTX_OWN_STREAM, &ctx)
-            precondition(status == 0, "jpeg_amd_ctx_create: \(String(cString: jpeg_amd_strerror(status)))")
+            let status:Int32 = jpeg_amd_ctx_create(.init(device), nil, JPEG_AMD_CTX_OWN_STREAM, &ctx)
+            precondition(status == 0, "jpeg_amd_ctx_create(device \(device)): \(String(cString: jpeg_amd_strerror(status)))")
         }
         defer
         {
             pthread_mutex_lock(&Self.pool.lock)
-            Self.pool.free.append(ctx!)
+            Self.pool.free[device].append(ctx!)
             pthread_mutex_unlock(&Self.pool.lock)
         }
         return body(ctx!)
@@ -167,6 +223,56 @@ extension JPEG.Data.Spectral
             {
                 .init($0.0, units: self[$0.1].units, factor: self[$0.1].factor)
             })
+    }
+}
+
+extension JPEG.Data.Spectral where Format == JPEG.Common
+{
+    // JPEG.RGB and JPEG.YCbCr are three stored UInt8 each, declared in channel order (jpeg.swift:160-269): an array
+    // of them IS the byte layout uint8 [pixel][3] the C ABI writes.
+    private
+    func decode<Color>(_:Color.Type, color:jpeg_amd_color, cosited:Bool) -> [Color]
+    {
+        precondition(MemoryLayout<Color>.size == 3 && MemoryLayout<Color>.stride == 3 &&
+            MemoryLayout<Color>.alignment == 1, "\(Color.self) is not three packed bytes")
+        let units:[(x:Int, y:Int)] = self.indices.map{ self[$0].units }
+        var l:jpeg_amd_layout   = AMD.layout(self.layout, size: self.size, units: units,
+            q: self.indices.map{ self[$0].q })
+        let quanta:[UInt16]     = AMD.tables(self)
+        let n:Int               = self.size.x * self.size.y
+        var status:Int32        = 0
+        let pixels:[Color] = .init(unsafeUninitializedCapacity: n)
+        {
+            (buffer:inout UnsafeMutableBufferPointer<Color>, initialized:inout Int) in
+            let raw:UnsafeMutableRawBufferPointer = .init(buffer)
+            status = AMD.withPointers(self.indices.map{ self[$0].buffer })
+            {
+                (coef:[UnsafePointer<Int16>?]) -> Int32 in
+                AMD.withContext
+                {
+                    jpeg_amd_host_decode($0, &l, coef, quanta, .init(self.quanta.count), cosited ? 1 : 0, color,
+                        raw.baseAddress?.assumingMemoryBound(to: UInt8.self))
+                }
+            }
+            if status != 0 { raw.initializeMemory(as: UInt8.self, repeating: 0) }
+            initialized = n
+        }
+        AMD.check(status, "jpeg_amd_host_decode")
+        return pixels
+    }
+    /// `spectral.idct().interleaved(cosite:).unpack(as:)` (decode.swift:4154, 4182, 4294) in ONE call: the coefficient
+    /// planes cross PCIe once, the pixels once, and for ycc8 / y8 layouts the device runs its fused kernels (4:2:0: one
+    /// launch, no intermediate).  The three staged methods each upload their input and download their output; a host
+    /// that wants pixels from a Spectral should call this instead.  Same bytes as the staged chain, bit for bit.
+    public
+    func decode(as _:JPEG.RGB.Type, cosite cosited:Bool = false) -> [JPEG.RGB]
+    {
+        self.decode(JPEG.RGB.self, color: JPEG_AMD_COLOR_RGB8, cosited: cosited)
+    }
+    public
+    func decode(as _:JPEG.YCbCr.Type, cosite cosited:Bool = false) -> [JPEG.YCbCr]
+    {
+        self.decode(JPEG.YCbCr.self, color: JPEG_AMD_COLOR_YCC8, cosited: cosited)
     }
 }
 

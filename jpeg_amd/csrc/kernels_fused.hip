@@ -153,7 +153,7 @@ struct LumaArgs {
 // Waves per SIMD a variant is built for: what its LDS footprint admits (three workgroups of ~51 KiB per CU for grey; the
 // layouts with a full-width or full-height chroma tile and 4:4:4 need 58-75 KiB per workgroup: two).
 template <int SX, int SY, bool CHROMA>
-constexpr int luma_waves_per_simd() { return (CHROMA && (SX == 1 || SY == 1)) ? 2 : 3; }
+constexpr int luma_waves_per_simd() { return (CHROMA && SX != SY) ? 2 : 3; }
 
 template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX>
 __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) void k_luma_fused(LumaArgs a)
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     constexpr int NTAB = INSTRIP ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
-    __shared__ uint32_t scw[NW][INTHREAD ? 32 * 64 : 2 * PLANE];  // chroma samples under the strip (+ halo) / 4:4:4 stash
+    __shared__ uint32_t scw[NW][INTHREAD ? 1 : 2 * PLANE];  // chroma samples under the strip (+ halo); 4:4:4 keeps its own in registers
     __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
 
     const int lane0 = threadIdx.x & 63;
@@ -348,11 +348,14 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             }
         };
         read_block();
+        // 4:4:4: the work-item's own Cb / Cr samples, four to a dword, wait in 32 registers while the luma block is
+        // transformed (as 8 KiB of LDS per wave they held the kernel at two waves per SIMD)
+        uint32_t stash[2][INTHREAD ? 16 : 1];
         if constexpr (INTHREAD) {
             // Cb, then Cr: while one plane is transformed the next one's coefficients are on their
             // way into the (single) LDS buffer -- the block has to be in registers before the DMA
             // may overwrite it, hence the lgkmcnt wait
-#pragma unroll 1
+#pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 dma_strip(s, lane, pl == 0 ? 2 : 0);
@@ -366,8 +369,10 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
 #pragma unroll
                         for (int i = 0; i < 4; ++i)   // clamp [0, 255] + truncate == saturating convert of floor(v)
                             v = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 * d + i]), i, v);
-                        sc[(pl * 16 + 2 * y + d) * 64 + lane] = v;
+                        stash[pl][(2 * y + d) % (INTHREAD ? 16 : 1)] = v;
                     }
+#pragma unroll
+                for (int i = 0; i < (INTHREAD ? 16 : 1); ++i) asm volatile("" : "+v"(stash[pl][i]));
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 read_block();
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             if constexpr (SX == 2) {
                 r[0] = row[HX / 4 - 1 + lbx]; r[1] = row[HX / 4 + lbx]; r[2] = row[HX / 4 + 1 + lbx];
             } else if constexpr (INTHREAD) {   // the block's own samples, parked above
-                r[0] = sc[(pl * 16 + 2 * j) * 64 + lane]; r[1] = sc[(pl * 16 + 2 * j + 1) * 64 + lane]; r[2] = 0;
+                r[0] = stash[pl][(2 * j) % (INTHREAD ? 16 : 1)]; r[1] = stash[pl][(2 * j + 1) % (INTHREAD ? 16 : 1)]; r[2] = 0;
             } else {
                 r[0] = row[2 * lbx]; r[1] = row[2 * lbx + 1]; r[2] = 0;
             }

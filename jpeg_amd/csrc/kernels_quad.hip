@@ -209,13 +209,14 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         int img, syi, sxi;
         locate(stack_of(trip), img, syi, sxi);
 
-        // ---- modulated tables (only when the image changes) ----
-        if (img != img_of_table) {
+        // ---- modulated tables (only when they change: per image, or never when the batch shares one set) ----
+        const int table_id = a.quanta_stride == 0 ? 0 : img;
+        if (table_id != img_of_table) {
             const int qk = lane & 7, qh = lane >> 3;
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 sqw[wave][p][lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi[p] + zigzag_of(qk, qh)]);
-            img_of_table = img;
+            img_of_table = table_id;
         }
 
         // ---- the chroma pass's coefficients: wait for the DMA, read 8 x 16 B (swizzled).  VM operations retire in issue

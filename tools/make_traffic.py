@@ -4,7 +4,7 @@
 For every configuration (c3, c5, c2, c4) and every jpeg_amd kernel of it: launches, mean duration from the
 kernel trace, mean FETCH_SIZE / WRITE_SIZE per launch, and the bytes they stand for.  Unit and gfx950 correction as
 MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB; FETCH_SIZE tallies the 128-byte requests of
-16-B/lane streaming reads at 64 B, so it is doubled (the 4-B/lane chroma-row DMA of k_luma_fused is uncalibrated).
+16-B/lane streaming reads at 64 B, so it is doubled.
 The record is stamped with the commit and with digests of bench.py and of the decode kernels' sources: bench.py only
 reports `roofline.traffic` while the digest still matches (otherwise null)."""
 import csv, json, re, sys, os, collections, hashlib, subprocess
@@ -74,7 +74,7 @@ except Exception:
                                                    else "unknown (no .git on the GPU box; see the commit that adds this file)")
 print(json.dumps({
     "tag": tag, "commit": commit,
-    "kernel_source_sha16": sha16(["jpeg_amd/csrc/" + f for f in ("kernels_fused.hip", "dct.hpp", "upsample.hpp", "kernels.hpp")]),
+    "kernel_source_sha16": sha16(["jpeg_amd/csrc/" + f for f in ("kernels_quad.hip", "kernels_fused.hip", "fused_common.hpp", "dct.hpp", "upsample.hpp", "kernels.hpp", "capi.hip")]),   # = bench.DECODE_SOURCES
     "bench_sha16": sha16(["bench.py"]),
     "method": "rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over each "
               "configuration's command (tools/profile_round.sh); per-launch means; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 "

@@ -232,7 +232,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         // The scheduler of a SIMD issues its oldest ready wave first.  From the start of a strip to the arrival at the
         // "ready" counter a wave runs at the top priority (whoever arrives late is waited for by up to three others);
         // after it at most at priority 2, by strips left -- laggards catch up and the waves of a SIMD leave together.
+#if !defined(JA_X_PRIO) || JA_X_PRIO == 3
         __builtin_amdgcn_s_setprio(3);
+#elif JA_X_PRIO == 1    // experiment: by strips left only, no boost up to the arrival
+        { const int rem0 = trips - 1 - trip; if (rem0 >= 3) __builtin_amdgcn_s_setprio(3); else if (rem0 == 2) __builtin_amdgcn_s_setprio(2); else if (rem0 == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif JA_X_PRIO == 2    // experiment: low while transforming, high in the pixel rows (the phase that issues the stores)
+        __builtin_amdgcn_s_setprio(0);
+#endif
         uint32_t w[32];
         auto read_block = [&]() {
             const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
@@ -327,9 +333,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         JA_PHASE(4)
         {
             const int rem = trips - 1 - trip;   // strips after this one
+#if !defined(JA_X_PRIO) || JA_X_PRIO == 3
             if (rem >= 2) __builtin_amdgcn_s_setprio(2);
             else if (rem == 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
+#else
+            (void)rem;
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -423,6 +433,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
         stores_behind_dma = (FAST && full) ? kStoresBehind : 0;
+#if defined(JA_X_PRIO) && JA_X_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
         JA_PHASE(7)
 
         // One pixel row of the strip's BY block rows at a time, software-pipelined: row y is staged (ds_write) and read

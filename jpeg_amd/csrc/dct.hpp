@@ -209,6 +209,37 @@ __device__ __forceinline__ void idct_block_edge_row(const uint32_t (&w)[32], QPt
     idct8<true>(t, level, g);
 }
 
+// The first and the last COLUMN of idct_block (samples x = 0 and x = 7 of all eight rows): the first pass in full, of the
+// second pass only what outputs 0 and 7 need -- the same operations in the same order (idct8: r0 + s0, r0 - s0).
+template <typename QPtr>
+__device__ __forceinline__ void idct_block_edge_cols(const uint32_t (&w)[32], QPtr q, float level,
+                                                     float (&c0)[8], float (&c7)[8])
+{
+    float f[64];  // f[8*k + y]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float h[8], res[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh)
+            h[hh] = q[8 * hh + k] * coef_as_float(w, zigzag_of(k, hh));
+        idct8<false>(h, 0.0f, res);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) f[8 * k + y] = res[y];
+    }
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const float e  = level + f[8 * 0 + y];
+        const float a0 = e + f[8 * 4 + y];
+        const float b  = f[8 * 2 + y] + f[8 * 6 + y];
+        const float r0 = a0 + b;
+        const float d1 = f[8 * 1 + y] + f[8 * 7 + y];
+        const float d3 = f[8 * 5 + y] + f[8 * 3 + y];
+        const float s0 = d1 + d3;
+        c0[y] = r0 + s0;
+        c7[y] = r0 - s0;
+    }
+}
+
 // Planar.Plane.load + fdct8x8 -- encode.swift:80-99, 191-196.
 // g[8*y + x]: samples already min(limit, Float(sample)); out H[8*h + k] before quantise.
 __device__ __forceinline__ void fdct_block(const float (&g)[64], float level, float (&H)[64])

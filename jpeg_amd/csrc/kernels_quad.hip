@@ -63,8 +63,7 @@ struct QuadArgs {
 
 template <int BX> struct QuadShape {
     static constexpr int BY = 64 / BX;
-    static constexpr int QS = BX == 32 ? 4 : 2;           // strips (= waves) per stack
-    static constexpr int QG = (kThreads / 64) / QS;       // stacks per workgroup
+    static constexpr int QS = kThreads / 64;              // strips (= waves) per stack: one stack per workgroup
 };
 
 // MODE: 0 = YCbCr bytes, 1 = RGB bytes.  FAST: W % 16 == 0 and 16-byte aligned rows, so every 16-byte chunk of a row
@@ -72,100 +71,98 @@ template <int BX> struct QuadShape {
 template <int MODE, int BX, bool FAST>
 __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
 {
-    constexpr int BY = QuadShape<BX>::BY, QS = QuadShape<BX>::QS, QG = QuadShape<BX>::QG;
+    constexpr int BY = QuadShape<BX>::BY, QS = QuadShape<BX>::QS;
     constexpr int NW = kThreads / 64;
+    static_assert(QS == 4 && NW == 4, "the roles below are dealt to four waves");
     constexpr int CW = BX * 4, CR = BY * 4;               // chroma samples per strip row, chroma sample rows under a strip
-    constexpr int CBW = BX / 2, CBR = BY / 2;             // chroma blocks under a strip
+    constexpr int CBW = BX / 2, CBR = BY / 2;             // chroma blocks under a strip: CBR rows of CBW
     constexpr int PITCH = CW / 4 + 2;                     // dwords per tile row: one halo dword left, the samples, one right
-    constexpr int QROWS = QS * CR + 2;                    // sample rows of a stack's tile: halo, QS x CR rows, halo (34)
+    constexpr int QROWS = QS * CR + 2;                    // sample rows of the stack's tile: halo, QS x CR rows, halo (34 / 66)
     constexpr int PLANE = QROWS * PITCH;                  // dwords per plane of the tile
     constexpr int SEG_DW = BX * 6;                        // one pixel row of one block row: 24 B per block
     constexpr int CPS = SEG_DW / 4;                       // 16-byte chunks per such segment
-    // what work-item b of the wave at position qp transforms in the chroma pass:
-    //   0..31            the strip's own blocks: plane b >> 4, then row-major (b & 15) over CBR rows of CBW columns
-    //   32..47           the block row above the stack (first half of the stack's waves) or below it (second half), column
-    //                    b & (CBW - 1); the plane is the wave's parity (four waves: 16 columns each) or bit 3 of b (two waves)
-    //   48..48+4 CBR-1   left / right neighbours of the own rows: row (b - 48) >> 2, plane bit 1, side bit 0
-    //   then 4           the same two columns of the row above (first wave) / below (last wave) the stack: corner samples
-    constexpr int QCORN0 = 48 + 4 * CBR, QEND = QCORN0 + 4;
-    constexpr int NDMA_C = (QEND + 7) / 8;                // LDS-DMA instructions of a chroma pass (8 blocks each)
+    // The stack's chroma blocks are dealt to its four waves BY KIND (the wave's ROLE of the trip), not by strip:
+    //   role 0, 1   the 64 blocks under strips 0, 1 / 2, 3 of the stack (work-item b: strip b >> 5, plane (b >> 4) & 1, then
+    //               row-major over CBR rows of CBW columns): a full transform, all work-items busy;
+    //   role 2      the 4 CBW blocks above and below the stack (b / (2 CBW): above / below, plane, column), of which only
+    //               the last / first sample row is wanted: idct_block_edge_row, a third of a block's arithmetic;
+    //   role 3      the 4 (QS CBR + 2) neighbour blocks left and right (b >> 2: block row from the one above the stack to
+    //               the one below, plane (b >> 1) & 1, side b & 1), of which only the column that touches the stack is
+    //               wanted: idct_block_edge_cols, two thirds.
+    // 3.0 transform passes per stack of four strips where one pass per strip (own blocks + a share of the halo in every
+    // wave, round 2 / the first version of this kernel) is 4.0.  The roles swap between the wave pairs (0, 1) and (2, 3)
+    // every trip, so that every wave does the same work over two trips.
+    constexpr int NHROW = 4 * CBW, NSIDE = 4 * (QS * CBR + 2);   // blocks of role 2 / role 3: 64 / 24 (32 x 2 strips), 32 / 40
+    constexpr int NDMA_C = 8;                             // LDS-DMA instructions of a chroma pass at most (8 blocks each)
 
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];   // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
-    __shared__ uint32_t qtile[QG * 2 * PLANE];            // one tile per stack; row 0: halo above, rows 1 + CR p ...: wave p, last row: halo below
+    __shared__ uint32_t qt[2 * PLANE];                    // the stack's tile; row 0: halo above, rows 1 + CR p ...: strip p, last row: halo below
     __shared__ float sqw[NW][3][64];                      // modulated tables: Y, Cb, Cr
-    // per stack two monotonic counters.  [0] "ready": a wave has written its samples of this trip into the tile;
-    // [1] "done": a wave has read the last sample of this trip that another wave wrote.
-    __shared__ uint32_t qsync[2 * QG];
+    // two monotonic counters.  [0] "ready": a wave has written its samples of this trip into the tile;
+    // [1] "done": a wave has read the last sample of this trip.
+    __shared__ uint32_t qsync[2];
 
     const int lane0 = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // strip math stays scalar
-    const int qp = wave % QS, qg = wave / QS;             // position in the stack, stack of the workgroup
-    uint32_t *coef_w = coefbuf[wave], *stage_w = stage[wave];
+    const int qp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the wave's strip of the stack; strip math stays scalar
+    uint32_t *coef_w = coefbuf[qp], *stage_w = stage[qp];
     const uint32_t coef_lds = lds_address(coef_w);
-    uint32_t *qt = qtile + qg * 2 * PLANE;
     uint32_t *sc = qt + CR * qp * PITCH;                  // this wave's window: row 0 = the sample row above its own rows
-    uint32_t *ready = &qsync[2 * qg], *done = &qsync[2 * qg + 1];
+    uint32_t *ready = &qsync[0], *done = &qsync[1];
 
-    if (threadIdx.x < 2 * QG) qsync[threadIdx.x] = 0;
+    if (threadIdx.x < 2) qsync[threadIdx.x] = 0;
     __syncthreads();   // the only workgroup barrier of the walk
 
     FastDiv fd_spi, fd_tx;
     fd_spi.set((uint32_t)a.stacks_per_image); fd_tx.set((uint32_t)a.tiles_x);
-    // trip t of this workgroup: stack (blockIdx.x + t gridDim.x) QG + qg -> image, strip row of this wave, strip column
-    auto stack_of = [&](int t) -> int { return ((int)blockIdx.x + t * (int)gridDim.x) * QG + qg; };
+    // trip t of this workgroup: stack blockIdx.x + t gridDim.x -> image, strip row of this wave, strip column
+    auto stack_of = [&](int t) -> int { return (int)blockIdx.x + t * (int)gridDim.x; };
     auto locate = [&](int q, int &img, int &syi, int &sxi) {
         uint32_t rem, col;
         img = (int)fd_spi.div((uint32_t)q, rem);
         syi = QS * (int)fd_tx.div(rem, col) + qp;
         sxi = (int)col;
     };
-    const int trips = (a.nstacks - qg + (int)gridDim.x * QG - 1 - (int)blockIdx.x * QG) / ((int)gridDim.x * QG);   // stacks this wave's pair walks
-    if (stack_of(0) >= a.nstacks) return;
+    const int trips = (a.nstacks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // stacks this workgroup walks
+    const int strips_y = (a.uy + BY - 1) / BY;
+    auto role_of = [&](int t) -> int { return (qp + 2 * (t & 1)) & 3; };
 
-    auto quad_block = [&](int b, int syi, int sxi, int &pl, int &bx, int &by) {
-        const int top = syi - qp;                                           // strip row of the stack's first strip
-        const int above_row = CBR * top - 1, below_row = CBR * (top + QS);  // chroma block rows (clamped by the caller)
-        if (b < 32) { const int idx = b & 15; pl = b >> 4; bx = CBW * sxi + idx % CBW; by = CBR * syi + idx / CBW; }
-        else if (b < 48) { pl = BX == 32 ? (qp & 1) : ((b >> 3) & 1); bx = CBW * sxi + (b & (CBW - 1)); by = qp < QS / 2 ? above_row : below_row; }
-        else {
-            const int j = b < QCORN0 ? b - 48 : b - QCORN0;
-            pl = (j >> 1) & 1; bx = (j & 1) ? CBW * sxi + CBW : CBW * sxi - 1;
-            by = b < QCORN0 ? CBR * syi + (j >> 2) : (qp == 0 ? above_row : below_row);
-        }
-    };
     // LDS-DMA of a pass's blocks: instruction i moves 64 x 16 B; slot u = 64 i + lane holds chunk (u & 7) ^ ((b >> 1) & 7)
     // of block b = u >> 3 -- the XOR on the SOURCE address makes the later per-work-item ds_read_b128 (stride 128 B)
     // bank-conflict-free.  Where the eight blocks of an instruction are neighbours in a block row, the block index is
     // scalar and only the lane's place inside the group is per lane (`ve`; odd i: chunk ^ 4).
-    // `i`: the instruction (0 .. NDMA_C - 1 / 0 .. 7); the strip walks issue them one at a time between the columns of a
-    // transform (idct_block_hooked), the prologue all at once.
-    auto dma_chroma_one = [&](int i, int img, int syi, int sxi, int lane) {
+    auto dma_chroma_one = [&](int i, int img, int syi, int sxi, int lane, int role) {
         const uint32_t l3 = lane >> 3;
-        if (i < 6 && CBW * sxi + CBW <= a.uxc) {   // wave-uniform: the strip's chroma columns lie inside the plane
-            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
-            const int top = syi - qp;
-            const int halo_row = min(max(qp < QS / 2 ? CBR * top - 1 : CBR * (top + QS), 0), a.uyc - 1);   // missing rows: fetched, not used
-            int pl, row, col0;
-            if constexpr (BX == 32) { pl = i < 4 ? i >> 1 : (qp & 1); row = i < 4 ? syi : halo_row; col0 = 16 * sxi + 8 * (i & 1); }
-            else { pl = i < 4 ? i >> 1 : (i & 1); row = i < 4 ? 2 * syi + (i & 1) : halo_row; col0 = 8 * sxi; }
-            row = min(row, a.uyc - 1);
-            const uint64_t sb = reinterpret_cast<uint64_t>(a.coef[1 + pl] + img * a.coef_stride[1 + pl]) +
-                                ((uint64_t)((uint32_t)row * (uint32_t)a.uxc + (uint32_t)col0) << 7);
-            lds_dma16_s_keep(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
-            return;
-        }
         const int b = 8 * i + (int)l3;
-        int pl, bx, by;
-        if (BX == 32 && i == 6) {   // sides (48..51) and corners (52..55): the same map as quad_block with fewer branches
-            const int top = syi - qp;
-            pl = (b >> 1) & 1; bx = (b & 1) ? 16 * sxi + 16 : 16 * sxi - 1; by = b < 52 ? syi : (qp < 2 ? top - 1 : top + QS);
+        const int top = syi - qp;                             // strip row of the stack's first strip
+        int pl, bx, row;
+        if (role < 3) {   // runs of eight neighbouring blocks
+            int col0;
+            if (role < 2) {
+                if constexpr (BX == 32) { pl = (i >> 1) & 1; row = top + 2 * role + (i >> 2); col0 = 8 * (i & 1); }
+                else { pl = (i >> 1) & 1; row = CBR * (top + 2 * role + (i >> 2)) + (i & 1); col0 = 0; }
+            } else {
+                if (8 * i >= NHROW) return;
+                const int below = (8 * i) / (2 * CBW);
+                pl = ((8 * i) / CBW) & 1; col0 = (8 * i) % CBW;
+                row = below ? CBR * (top + QS) : CBR * top - 1;
+            }
+            row = min(max(row, 0), a.uyc - 1);   // missing rows: fetched, not used
+            if (CBW * sxi + CBW <= a.uxc) {   // wave-uniform: the strip's chroma columns lie inside the plane
+                const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+                const uint64_t sb = reinterpret_cast<uint64_t>(a.coef[1 + pl] + img * a.coef_stride[1 + pl]) +
+                                    ((uint64_t)((uint32_t)row * (uint32_t)a.uxc + (uint32_t)(CBW * sxi + col0)) << 7);
+                lds_dma16_s_keep(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+                return;
+            }
+            bx = CBW * sxi + col0 + (int)l3;
         } else {
-            quad_block(b, syi, sxi, pl, bx, by);
+            if (8 * i >= NSIDE) return;
+            pl = (b >> 1) & 1; row = min(max(CBR * top - 1 + (b >> 2), 0), a.uyc - 1);
+            bx = (b & 1) ? CBW * sxi + CBW : CBW * sxi - 1;
         }
-        by = min(max(by, 0), a.uyc - 1);   // missing rows: fetched, not used
         const int16_t *cbase = a.coef[1 + pl] + img * a.coef_stride[1 + pl];
-        const uint32_t blk = (bx >= 0 && bx < a.uxc) ? (uint32_t)by * a.uxc + bx : 0u;
+        const uint32_t blk = (bx >= 0 && bx < a.uxc) ? (uint32_t)row * a.uxc + bx : 0u;   // outside the plane: fetched, not used
         const int c = (lane & 7) ^ ((b >> 1) & 7);
         lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
     };
@@ -190,11 +187,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
 #ifdef JA_X_STAGGER   // experiment: the three workgroups of a CU start a third of a strip apart
     for (int d = (int)(blockIdx.x / 256u) * (JA_X_STAGGER); d > 0; d -= 64 * 100) __builtin_amdgcn_s_sleep(100);
 #endif
+    if (trips <= 0) return;
     {
         int img, syi, sxi;
         locate(stack_of(0), img, syi, sxi);
 #pragma unroll
-        for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, img, syi, sxi, lane0);
+        for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, img, syi, sxi, lane0, role_of(0));
     }
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
@@ -208,6 +206,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         const int lbx = lane & (BX - 1), seg = (int)((unsigned)lane / BX);
         int img, syi, sxi;
         locate(stack_of(trip), img, syi, sxi);
+        // a strip below the image (the last stack of an image may be short): the wave still plays its role in the chroma
+        // pass and keeps the counters, but has no luma blocks and no pixels
+        const bool phantom = syi >= strips_y;
 
         // ---- modulated tables (only when they change: per image, or never when the batch shares one set) ----
         const int table_id = a.quanta_stride == 0 ? 0 : img;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
             const int qk = lane & 7, qh = lane >> 3;
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                sqw[wave][p][lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi[p] + zigzag_of(qk, qh)]);
+                sqw[qp][p][lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi[p] + zigzag_of(qk, qh)]);
             img_of_table = table_id;
         }
 
@@ -223,22 +224,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         //      order and the DMA was issued BEFORE the previous strip's pixel stores: when that strip took the branch-free
         //      store path (exactly 2 store instructions per pixel row) only the DMA has to be waited for ----
         if (stores_behind_dma == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (stores_behind_dma == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (stores_behind_dma == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (stores_behind_dma == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (stores_behind_dma == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         JA_PHASE(0)
         // The scheduler of a SIMD issues its oldest ready wave first.  From the start of a strip to the arrival at the
-        // "ready" counter a wave runs at the top priority (whoever arrives late is waited for by up to three others);
+        // "ready" counter a wave runs at the top priority (whoever arrives late is waited for by the others);
         // after it at most at priority 2, by strips left -- laggards catch up and the waves of a SIMD leave together.
-#if !defined(JA_X_PRIO) || JA_X_PRIO == 3
         __builtin_amdgcn_s_setprio(3);
-#elif JA_X_PRIO == 1    // experiment: by strips left only, no boost up to the arrival
-        { const int rem0 = trips - 1 - trip; if (rem0 >= 3) __builtin_amdgcn_s_setprio(3); else if (rem0 == 2) __builtin_amdgcn_s_setprio(2); else if (rem0 == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif JA_X_PRIO == 2    // experiment: low while transforming, high in the pixel rows (the phase that issues the stores)
-        __builtin_amdgcn_s_setprio(0);
-#endif
         uint32_t w[32];
         auto read_block = [&]() {
             const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
@@ -253,8 +244,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         const uint32_t done_seen = lds_peek(done);   // checked after the transform; read here so that the check costs no round trip
         // w holds the chroma pass's block; the luma blocks of the strip follow it into the buffer
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!phantom) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dma_luma_one(i, img, syi, sxi, lane);
+            for (int i = 0; i < 8; ++i) dma_luma_one(i, img, syi, sxi, lane);
+        }
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(1)
 
@@ -262,62 +255,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         const bool stack_above = top > 0, stack_below = CBR * (top + QS) < a.uyc;   // uniform over the stack
         const bool has_left = sxi > 0, has_right = CBW * sxi + CBW < a.uxc;
         const int first_bad = (a.uxc << 1) - sxi * (CW / 4) + 1;   // first tile dword past the plane (PITCH - 1 at a full last tile)
-        {
-            int pl, bx_, by_;
-            quad_block(lane, syi, sxi, pl, bx_, by_);
-            float g[64];
-#ifdef JA_X_NOCIDCT   // experiment (wrong pixels): the walk without the arithmetic of its chroma transform
-#pragma unroll
-            for (int i = 0; i < 64; ++i) g[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff) + sqw[wave][1 + pl][i];
-#else
-            idct_block(w, sqw[wave][1 + pl], 128.5f, g);
-#endif
-            // clamp [0, 255] + truncate == saturating convert of floor(v); every work-item packs its whole block (one
-            // instruction stream for the three kinds of block), what is stored where differs
-            uint32_t pk[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                uint32_t d = 0;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) d = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[4 * i + x]), x, d);
-                pk[i] = d;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pk[i]));
-            JA_PHASE(2)
-            // everyone has read the previous trip's tile before anyone overwrites it: the others signalled "done" two pixel
-            // rows before the end of their previous strip, more than a transform ago -- this rarely waits
-            lds_wait_ge_seen(done, (uint32_t)(QS * trip), done_seen);
-            JA_PHASE(3)
-            uint32_t *tile = qt + pl * PLANE;
-            if (lane < 32) {
-                const int idx = lane & 15;
-                uint32_t *dst = tile + (1 + CR * qp + 8 * (idx / CBW)) * PITCH + 1 + 2 * (idx % CBW);
-#pragma unroll
-                for (int y = 0; y < 8; ++y) { dst[y * PITCH] = pk[2 * y]; dst[y * PITCH + 1] = pk[2 * y + 1]; }
-            } else if (lane < 48) {
-                const bool above = qp < QS / 2;
-                if (above ? stack_above : stack_below) {
-                    uint32_t *dst = tile + (above ? 0 : QROWS - 1) * PITCH + 1 + 2 * (lane & (CBW - 1));
-                    dst[0] = above ? pk[14] : pk[0];     // last row of the block above / first row of the block below
-                    dst[1] = above ? pk[15] : pk[1];
-                }
-            } else if (lane < QEND) {
-                const int j = lane < QCORN0 ? lane - 48 : lane - QCORN0, side = j & 1;
-                // the neighbour's edge sample, replicated: first column of the block to the right, last of the block to the left
-                auto rep = [&](int y) -> uint32_t { return side ? (pk[2 * y] & 0xffu) * 0x01010101u : (pk[2 * y + 1] >> 24) * 0x01010101u; };
-                if (side ? has_right : has_left) {
-                    uint32_t *col = tile + (side ? PITCH - 1 : 0);
-                    if (lane < QCORN0) {
-#pragma unroll
-                        for (int y = 0; y < 8; ++y) col[(1 + CR * qp + 8 * (j >> 2) + y) * PITCH] = rep(y);
-                    } else if (qp == 0 && stack_above) col[0] = rep(7);
-                    else if (qp == QS - 1 && stack_below) col[(QROWS - 1) * PITCH] = rep(0);
-                }
-            }
-        }
-        // the plane's left / right edge: the reference clamps the sample index (decode.swift:4245) -- own rows here, the two
-        // halo rows after the wait for the tile (their samples come from other waves)
+        // the plane's left / right edge: the reference clamps the sample index (decode.swift:4245)
         auto fix_columns = [&](uint32_t *row) {
             if (!has_left) row[0] = (row[1] & 0xffu) * 0x01010101u;
             if (first_bad < PITCH) {
@@ -325,21 +263,102 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 for (int c = first_bad; c < PITCH; ++c) row[c] = last;
             }
         };
-        if (!has_left || first_bad < PITCH) {
-            if (lane < 2 * CR) fix_columns(qt + (lane / CR) * PLANE + (1 + CR * qp + lane % CR) * PITCH);
+        {
+            // ---- the chroma pass, by role.  Three complete code paths with nothing merged behind them: with a common
+            //      tail LLVM keeps the values of several transforms alive across the branches and spills.  clamp [0, 255]
+            //      + truncate == saturating convert of floor(v).  Before its samples go into the tile a wave checks that
+            //      everyone has read the previous trip's: the others signalled "done" two pixel rows before the end of
+            //      their previous strip, more than a transform ago -- this rarely waits. ----
+            const int role = role_of(trip);
+            const int pl = role < 2 ? (lane >> 4) & 1 : role == 2 ? (lane / CBW) & 1 : (lane >> 1) & 1;
+            uint32_t *tile = qt + pl * PLANE;
+            if (role < 2) {
+                float g[64];
+#ifdef JA_X_NOCIDCT   // experiment (wrong pixels): the walk without the arithmetic of its chroma transform
+#pragma unroll
+                for (int i = 0; i < 64; ++i) g[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff) + sqw[qp][1 + pl][i];
+#else
+                idct_block(w, sqw[qp][1 + pl], 128.5f, g);
+#endif
+                uint32_t pk[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    uint32_t d = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) d = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[4 * i + x]), x, d);
+                    pk[i] = d;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pk[i]));
+                JA_PHASE(2)
+                lds_wait_ge_seen(done, (uint32_t)(QS * trip), done_seen);
+                JA_PHASE(3)
+                const int idx = lane & 15;
+                uint32_t *dst = tile + (1 + CR * (2 * role + (lane >> 5)) + 8 * (idx / CBW)) * PITCH + 1 + 2 * (idx % CBW);
+#pragma unroll
+                for (int y = 0; y < 8; ++y) { dst[y * PITCH] = pk[2 * y]; dst[y * PITCH + 1] = pk[2 * y + 1]; }
+                // the edge columns of the rows this wave has just written, at the plane's left / right edge
+                if (!has_left || first_bad < PITCH) {
+                    if (lane < 4 * CR) fix_columns(qt + (lane / (2 * CR)) * PLANE + (1 + 2 * CR * role + lane % (2 * CR)) * PITCH);
+                }
+            } else if (role == 2) {   // above: the block's last sample row; below: its first
+                const bool below = lane >= 2 * CBW;
+                float r[8];
+                idct_block_edge_row(w, sqw[qp][1 + pl], 128.5f, !below, r);
+                uint32_t p0 = 0, p1 = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { p0 = __builtin_amdgcn_cvt_pk_u8_f32(floorf(r[x]), x, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(floorf(r[4 + x]), x, p1); }
+                asm volatile("" : "+v"(p0), "+v"(p1));
+                JA_PHASE(2)
+                lds_wait_ge_seen(done, (uint32_t)(QS * trip), done_seen);
+                JA_PHASE(3)
+                if (lane < NHROW && (below ? stack_below : stack_above)) {
+                    uint32_t *dst = tile + (below ? QROWS - 1 : 0) * PITCH + 1 + 2 * (lane % CBW);
+                    dst[0] = p0; dst[1] = p1;
+                }
+            } else {   // neighbour blocks: the column that touches the stack (first of the right, last of the left neighbour)
+                const int rowi = lane >> 2, side = lane & 1;
+                float c0[8], c7[8];
+                idct_block_edge_cols(w, sqw[qp][1 + pl], 128.5f, c0, c7);
+                uint32_t e[8];   // the edge sample of each row, replicated
+#pragma unroll
+                for (int y = 0; y < 8; ++y) e[y] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(side ? c0[y] : c7[y]), 0, 0u) * 0x01010101u;
+#pragma unroll
+                for (int y = 0; y < 8; ++y) asm volatile("" : "+v"(e[y]));
+                JA_PHASE(2)
+                lds_wait_ge_seen(done, (uint32_t)(QS * trip), done_seen);
+                JA_PHASE(3)
+                if (lane < NSIDE && (side ? has_right : has_left)) {
+                    uint32_t *col = tile + (side ? PITCH - 1 : 0);
+                    if (rowi == 0) { if (stack_above) col[0] = e[7]; }                                  // corner samples
+                    else if (rowi == QS * CBR + 1) { if (stack_below) col[(QROWS - 1) * PITCH] = e[0]; }
+                    else {
+#pragma unroll
+                        for (int y = 0; y < 8; ++y) col[(1 + 8 * (rowi - 1) + y) * PITCH] = e[y];
+                    }
+                }
+            }
         }
-        // this wave's samples are in the tile: arrive, do not wait
+        // this wave's samples are in the tile: arrive, do not wait yet
         lds_arrive(ready, lane);
         JA_PHASE(4)
         {
             const int rem = trips - 1 - trip;   // strips after this one
-#if !defined(JA_X_PRIO) || JA_X_PRIO == 3
             if (rem >= 2) __builtin_amdgcn_s_setprio(2);
             else if (rem == 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
-#else
-            (void)rem;
-#endif
+        }
+        const bool more = trip + 1 < trips;
+        int n_img = 0, n_syi = 0, n_sxi = 0;
+        if (more) locate(stack_of(trip + 1), n_img, n_syi, n_sxi);
+        if (phantom) {   // nothing to decode: the next pass's blocks, both counters, next trip
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, n_img, n_syi, n_sxi, lane, role_of(trip + 1));
+            }
+            lds_arrive(done, lane);
+            stores_behind_dma = 0;
+            continue;
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -348,43 +367,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         // ---- the coefficient buffer is consumed: prefetch the next stack's chroma pass into it.  From here to the end of
         //      the strip only stores are issued, so nothing waits on the DMA.  (One DMA instruction in front of each column of
         //      the transform instead of eight in a row, pinned with scheduling barriers, costs the transform more than the
-        //      burst costs: a column alone has too little instruction-level parallelism -- 88 against 86 us.) ----
+        //      burst costs; one or two per pixel row change nothing: profiles/r03_ab_*dma*.txt.) ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         JA_PHASE(12)
-        const bool more = trip + 1 < trips;
-        int n_img = 0, n_syi = 0, n_sxi = 0;
-        if (more) locate(stack_of(trip + 1), n_img, n_syi, n_sxi);
-#ifdef JA_X_PACED   // experiment: the prefetch issued two instructions at a time in front of the first pixel rows
-        constexpr int kPace = JA_X_PACED;
-#else
-        constexpr int kPace = 0;
         if (more) {
 #pragma unroll
-            for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, n_img, n_syi, n_sxi, lane);
+            for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, n_img, n_syi, n_sxi, lane, role_of(trip + 1));
         }
-#endif
-        auto pace = [&](int idx) {
-            if constexpr (kPace > 0) {
-#pragma unroll
-                for (int i = kPace * idx; i < kPace * idx + kPace; ++i)
-                    if (i < NDMA_C && more) dma_chroma_one(i, n_img, n_syi, n_sxi, lane);
-            }
-        };
-        constexpr int kPaceSteps = kPace > 0 ? (NDMA_C + kPace - 1) / kPace : 0;        // steps that issue DMA instructions
-        constexpr int kStoresBehind = kPace > 0 ? 2 * (8 - (kPaceSteps - 1) + 1) : 16;     // store instructions behind the last one
+        const uint32_t ready_seen = lds_peek(ready);
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(13)
-        // the chroma dwords of the first three patch rows the pixel rows need (the wave's own samples): requested here, they
-        // land during the transform
-        uint32_t raw1[2][3], raw2[2][3], rawn[2][3], raw0[2][3];
-        auto hraw = [&](int pl, int j, uint32_t (&r)[3]) {
-            const uint32_t *row = sc + pl * PLANE + (seg * 4 + j) * PITCH;
-            r[0] = row[lbx]; r[1] = row[1 + lbx]; r[2] = row[2 + lbx];
-        };
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) { hraw(pl, 1, raw1[pl]); hraw(pl, 2, raw2[pl]); hraw(pl, 3, rawn[pl]); }
-        __builtin_amdgcn_sched_barrier(0);
-        JA_PHASE(5)
 
         // ---- luma: dequantise + IDCT, clamp + truncate (decode.swift:4121-4122), kept as integer-valued floats ----
         float yv[64];
@@ -392,7 +384,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
 #pragma unroll
         for (int i = 0; i < 64; ++i) yv[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff);
 #else
-        idct_block(w, sqw[wave][0], 128.5f, yv);
+        idct_block(w, sqw[qp][0], 128.5f, yv);
 #pragma unroll
         for (int i = 0; i < 64; ++i) yv[i] = floorf(__builtin_amdgcn_fmed3f(yv[i], 0.0f, 255.0f));
 #endif
@@ -402,9 +394,34 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(6)
 
+        // ---- the stack's tile is complete: everyone's samples of this trip are in it (the wave arrived a luma transform
+        //      ago; it was read then so that the check costs no round trip) ----
+        lds_wait_ge_seen(ready, (uint32_t)(QS * (trip + 1)), ready_seen);
+        JA_PHASE(9)
+        {
+            // the sample row above the wave's first / below its last where it is not in the plane: image top / bottom (a
+            // missing row is the nearest own row, decode.swift:4246), and the edge columns of the stack's two halo rows
+            // (decode.swift:4245).  Only this wave reads the rows it repairs.
+            const int rows_avail = 8 * (a.uyc - CBR * syi);   // chroma sample rows of the plane from the first one under this strip
+            auto copy_row = [&](int dst, int src) {          // rows of the wave's window, both planes
+                for (int d = lane; d < 2 * PITCH; d += 64) {
+                    uint32_t *col = sc + (d >= PITCH ? PLANE + d - PITCH : d);
+                    col[dst * PITCH] = col[src * PITCH];
+                }
+            };
+            if (syi == 0) copy_row(0, 1);
+            else if (qp == 0 && (!has_left || first_bad < PITCH) && lane < 2) fix_columns(qt + lane * PLANE);
+            if (rows_avail > 0 && rows_avail <= CR) copy_row(rows_avail + 1, rows_avail);
+            else if (qp == QS - 1 && (!has_left || first_bad < PITCH) && lane < 2) fix_columns(qt + lane * PLANE + (QROWS - 1) * PITCH);
+        }
+
         // ---- chroma rows, produced just in time from the tile.  Patch row j of a block: window row seg (8 / 2) + j;
         //      the LDS reads (hraw) and the conversion + horizontal interpolation (hconv) are separate so that the reads
         //      can be issued well ahead of their use ----
+        auto hraw = [&](int pl, int j, uint32_t (&r)[3]) {
+            const uint32_t *row = sc + pl * PLANE + (seg * 4 + j) * PITCH;
+            r[0] = row[lbx]; r[1] = row[1 + lbx]; r[2] = row[2 + lbx];
+        };
         auto hconv = [&](const uint32_t (&r)[3], float (&o)[8]) {   // samples enter as 2^15 + p + 1/32 (upsample.hpp)
             const float p[6] = {ubyte_magic<3>(r[0]), ubyte_magic<0>(r[1]), ubyte_magic<1>(r[1]),
                                 ubyte_magic<2>(r[1]), ubyte_magic<3>(r[1]), ubyte_magic<0>(r[2])};
@@ -414,10 +431,15 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         auto finish = [&](float v) -> float {
             return __builtin_fmaf(v, 0.0625f, kMagic - 32768.0f - (MODE == 1 ? 128.0f : 0.0f)) - kMagic;
         };
-        // slot 0 = patch row 1 (kept for pixel row 0), slots 1 / 2 the sliding pair
+        // sliding window over the patch rows: slots hold rows (y >> 1), (y >> 1) + 1, (y >> 1) + 2
         float hw[2][3][8];
+        uint32_t rawn[2][3];
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) { hconv(raw1[pl], hw[pl][0]); hconv(raw2[pl], hw[pl][1]); }
+        for (int pl = 0; pl < 2; ++pl) {
+            uint32_t r0[3], r1[3];
+            hraw(pl, 0, r0); hraw(pl, 1, r1); hraw(pl, 2, rawn[pl]);
+            hconv(r0, hw[pl][0]); hconv(r1, hw[pl][1]);
+        }
 
         // ---- store geometry: per pixel row the strip's BY segments are 96 chunks of 16 B; a lane stores chunk `lane` (and
         //      lanes 0..31 also chunk 64 + lane).  Both store instructions of a row cover whole 128-byte lines. ----
@@ -432,15 +454,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = sg1 * 8u * pitch + 16u * j1;
         const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
-        stores_behind_dma = (FAST && full) ? kStoresBehind : 0;
-#if defined(JA_X_PRIO) && JA_X_PRIO == 2
-        __builtin_amdgcn_s_setprio(3);
-#endif
+        stores_behind_dma = (FAST && full) ? 16 : 0;
         JA_PHASE(7)
 
         // One pixel row of the strip's BY block rows at a time, software-pipelined: row y is staged (ds_write) and read
         // back as 16-byte chunks (ds_read) right after its arithmetic, but the chunks are stored only after the arithmetic
-        // of the next row.
+        // of the next row; the chroma dwords of the next patch row are requested two rows ahead.
         uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = make_uint4(0, 0, 0, 0);   // chunks of the previous pixel row
         auto put = [&](uint8_t *o, const uint4 &v, int j) {
             if constexpr (FAST) {
@@ -464,17 +483,22 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);
             }
         };
-        // pixel row y of the work-item's block: vertical interpolation (the nearer patch row weighs 3), colour, pack; then the
-        // row's traffic: the previous row's stores, this row's staging
-        auto step = [&](int idx, int y, int near, int far, int prev) __attribute__((always_inline)) {
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {  // pixel row y of every block row of the strip
             __builtin_amdgcn_sched_barrier(0);
-            pace(idx);
-            __builtin_amdgcn_sched_barrier(0);
+            // vertical interpolation: the nearer patch row (the middle of the window) weighs 3, the farther one (above
+            // for even y, below for odd) 1; then colour and pack
             float cv[2][8];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < 2; ++pl) {
+                if ((y & 1) == 1) hconv(rawn[pl], hw[pl][2]);
 #pragma unroll
-                for (int x = 0; x < 8; ++x) cv[pl][x] = finish(w31(hw[pl][near][x], hw[pl][far][x]));
+                for (int x = 0; x < 8; ++x) cv[pl][x] = finish(w31(hw[pl][1][x], hw[pl][(y & 1) ? 2 : 0][x]));
+                if ((y & 1) == 1) {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) { hw[pl][0][x] = hw[pl][1][x]; hw[pl][1][x] = hw[pl][2][x]; }
+                }
+            }
             uint32_t d[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
@@ -499,64 +523,27 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 d[(3 * x + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c2, (3 * x + 2) & 3, d[(3 * x + 2) >> 2]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (prev >= 0) store_row(prev);
+            // the row's traffic: the previous row's stores, this row's staging, the request for the next patch row
+            if (y > 0) store_row(y - 1);
             uint2 *sw = reinterpret_cast<uint2 *>(stage_w + seg * SEG_DW + lbx * 6);
             sw[0] = make_uint2(d[0], d[1]);
             sw[1] = make_uint2(d[2], d[3]);
             sw[2] = make_uint2(d[4], d[5]);
             pv0 = *reinterpret_cast<const uint4 *>(stage_w + 4 * lane);
             pv1 = *reinterpret_cast<const uint4 *>(stage_w + 4 * (64 + (lane & 31)));
-        };
-        // Rows in the order 1 2 3 4 5 6 | 0 7: only row 0 of the strip's first block row reads the sample row above the wave's
-        // own (patch row 0) and only row 7 of its last block row the one below (patch row 5) -- samples other waves produce.
-        step(0, 1, 0, 1, -1);                                    // patch rows 1 (near), 2
-        step(1, 2, 1, 0, 1);                                     // 2, 1
+            if ((y & 1) == 1 && y < 7) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][2]);   // patch row 3
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) hraw(pl, 4, rawn[pl]);
-        step(2, 3, 1, 2, 2);                                     // 2, 3
-        step(3, 4, 2, 1, 3);                                     // 3, 2
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][1]);   // patch row 4 (row 2 is dead)
-        const uint32_t ready_seen = lds_peek(ready);
-        step(4, 5, 2, 1, 4);                                     // 3, 4
-        JA_PHASE(8)
-        // ---- the stack's tile is complete: everyone's samples of this trip are in it ----
-        lds_wait_ge_seen(ready, (uint32_t)(QS * (trip + 1)), ready_seen);
-        JA_PHASE(9)
-        {
-            // the sample row above the wave's first / below its last, where it is not another wave's: image top / bottom (a
-            // missing row is the nearest own row, decode.swift:4246), and the edge columns of the stack's two halo rows
-            // (decode.swift:4245; their samples came from other waves).  Only this wave reads the rows it repairs.
-            const int rows_avail = 8 * (a.uyc - CBR * syi);   // chroma sample rows of the plane from the first one under this strip
-            auto copy_row = [&](int dst, int src) {          // rows of the wave's window, both planes
-                for (int d = lane; d < 2 * PITCH; d += 64) {
-                    uint32_t *col = sc + (d >= PITCH ? PLANE + d - PITCH : d);
-                    col[dst * PITCH] = col[src * PITCH];
-                }
-            };
-            if (syi == 0) copy_row(0, 1);
-            else if (qp == 0 && (!has_left || first_bad < PITCH) && lane < 2) fix_columns(qt + lane * PLANE);
-            if (rows_avail > 0 && rows_avail <= CR) copy_row(rows_avail + 1, rows_avail);
-            else if (qp == QS - 1 && (!has_left || first_bad < PITCH) && lane < 2) fix_columns(qt + lane * PLANE + (QROWS - 1) * PITCH);
+                for (int pl = 0; pl < 2; ++pl) hraw(pl, (y >> 1) + 3, rawn[pl]);
+                // after the request for patch row 5 the wave reads nothing more from the tile (the LDS performs the reads
+                // before the add)
+                if (y == 5) lds_arrive(done, lane);
+            }
         }
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) { hraw(pl, 0, raw0[pl]); hraw(pl, 5, rawn[pl]); }
-        // those were this trip's last reads of samples another wave wrote (the LDS performs them before the add)
-        lds_arrive(done, lane);
-        step(5, 6, 1, 2, 5);                                     // 4, 3
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) hconv(raw0[pl], hw[pl][2]);   // patch row 0 (row 3 is dead)
-        step(6, 0, 0, 2, 6);                                     // 1, 0
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) hconv(rawn[pl], hw[pl][2]);   // patch row 5
-        step(7, 7, 1, 2, 0);                                     // 4, 5
         __builtin_amdgcn_sched_barrier(0);
         store_row(7);
         JA_PHASE(10)
     }
-    JA_PHASE_FLUSH((int)blockIdx.x * NW + wave, lane0)
+    JA_PHASE_FLUSH((int)blockIdx.x * NW + qp, lane0)
 }
 
 // Persistent grid = what is resident at once (LDS-bound: three workgroups per CU).
@@ -581,8 +568,7 @@ hipError_t launch_quad(hipStream_t stream, const QuadArgs &a)
 #ifdef JA_PHASE_PROFILE   // development aid: JA_GRID_CAP=256 runs one workgroup per CU (a wave alone on its SIMD)
     if (const char *e = std::getenv("JA_GRID_CAP")) cap = std::min(cap, std::atoi(e));
 #endif
-    const int wgs = (a.nstacks + QuadShape<BX>::QG - 1) / QuadShape<BX>::QG;
-    hipLaunchKernelGGL((k_quad420<MODE, BX, FAST>), dim3(std::min(wgs, cap)), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL((k_quad420<MODE, BX, FAST>), dim3(std::min(a.nstacks, cap)), dim3(kThreads), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -633,7 +619,7 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
     a.uxc = L.units_x[1]; a.uyc = L.units_y[1];
     a.W = L.width; a.H = L.height;
     a.out = d_pixels; a.out_stride = pixel_stride;
-    const int bx = quad_strip_width(a.ux, a.uy), by = 64 / bx, qs = bx == 32 ? 4 : 2;
+    const int bx = quad_strip_width(a.ux, a.uy), by = 64 / bx, qs = 4;
     a.tiles_x = (a.ux + bx - 1) / bx;
     const int strips_y = (a.uy + by - 1) / by, stacks_y = (strips_y + qs - 1) / qs;
     a.stacks_per_image = a.tiles_x * stacks_y;

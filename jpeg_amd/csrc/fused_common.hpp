@@ -103,6 +103,106 @@ __device__ __forceinline__ void lds_wait_ge_seen(uint32_t *counter, uint32_t tar
     asm volatile("" ::: "memory");
 }
 
+// ---- clamp [0, 255] + truncate + pack, the reference's float -> byte conversion (decode.swift:4121-4122, jpeg.swift:343-354)
+// in ONE instruction per sample.  v_cvt_pk_u8_f32 saturates and rounds in the wave's f32 rounding mode
+// (tools/probe_cvt_round.hip, profiles/r03_probe_cvt_round.txt): under round-toward-zero it truncates, where the default
+// mode needs a v_floor_f32 in front of it (two half-rate instructions per sample).  The mode is switched and restored
+// inside one asm statement, so nothing the compiler schedules can land between the two s_setreg; the f32 instructions
+// right before and right after the statement keep round-to-nearest (tools/probe_cvt_round2.hip).
+// c: 4 n floats, d: n dwords (byte i of d[k] = c[4 k + i]).
+#ifdef JA_X_NOSETREG   // experiment (wrong pixels): the packs without the two mode switches
+#define JA_RTZ_ON ""
+#define JA_RTZ_OFF ""
+#else
+#define JA_RTZ_ON "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+#define JA_RTZ_OFF "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+#endif
+__device__ __forceinline__ void trunc_pack8(const float *c, uint32_t *d)
+{
+    asm volatile(JA_RTZ_ON
+                 "v_cvt_pk_u8_f32 %0, %2, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %6, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 3, %1\n\t"
+                 JA_RTZ_OFF
+                 : "=&v"(d[0]), "=&v"(d[1])
+                 : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+}
+__device__ __forceinline__ void trunc_pack16(const float *c, uint32_t *d)
+{
+    asm volatile(JA_RTZ_ON
+                 "v_cvt_pk_u8_f32 %0, %4, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %7, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %11, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %12, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %13, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %15, 3, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %16, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %3, %17, 1, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %18, 2, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %19, 3, %3\n\t"
+                 JA_RTZ_OFF
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                 : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]));
+}
+__device__ __forceinline__ void trunc_pack24(const float *c, uint32_t *d)
+{
+    asm volatile(JA_RTZ_ON
+                 "v_cvt_pk_u8_f32 %0, %6, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %7, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %8, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %9, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %11, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %12, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %1, %13, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %15, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %16, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %2, %17, 3, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %18, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %3, %19, 1, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %20, 2, %3\n\t"
+                 "v_cvt_pk_u8_f32 %3, %21, 3, %3\n\t"
+                 "v_cvt_pk_u8_f32 %4, %22, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %4, %23, 1, %4\n\t"
+                 "v_cvt_pk_u8_f32 %4, %24, 2, %4\n\t"
+                 "v_cvt_pk_u8_f32 %4, %25, 3, %4\n\t"
+                 "v_cvt_pk_u8_f32 %5, %26, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %5, %27, 1, %5\n\t"
+                 "v_cvt_pk_u8_f32 %5, %28, 2, %5\n\t"
+                 "v_cvt_pk_u8_f32 %5, %29, 3, %5\n\t"
+                 JA_RTZ_OFF
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+                 : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]), "v"(c[9]), "v"(c[10]), "v"(c[11]), "v"(c[12]), "v"(c[13]), "v"(c[14]), "v"(c[15]), "v"(c[16]), "v"(c[17]), "v"(c[18]), "v"(c[19]), "v"(c[20]), "v"(c[21]), "v"(c[22]), "v"(c[23]));
+}
+// eight samples, each into byte 0 of its own dword (the other bytes 0)
+__device__ __forceinline__ void trunc_bytes8(const float *c, uint32_t *d)
+{
+    asm volatile(JA_RTZ_ON
+                 "v_cvt_pk_u8_f32 %0, %8, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %10, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %3, %11, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %4, %12, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %5, %13, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %6, %14, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %7, %15, 0, 0\n\t"
+                 JA_RTZ_OFF
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+                 : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+}
+
 #ifdef JA_PHASE_PROFILE
 // development aid (tools/phase_profile.py): wall cycles each wave spends per phase of a strip
 constexpr int kPhaseSlots = 16;   // 0..13 phases, 14 the wave's life in shader cycles, 15 in ticks of the 100 MHz counter

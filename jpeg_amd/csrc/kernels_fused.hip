@@ -89,17 +89,10 @@ __global__ __launch_bounds__(kThreads) void k_chroma_idct(ChromaArgs a)
 
     const size_t pitch = (size_t)8 * a.ux;
     uint8_t *dst = a.out[pl] + img * a.out_stride + (size_t)8 * by * pitch + 8 * bx;
+    uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
+    trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
 #pragma unroll
-    for (int y = 0; y < 8; ++y) {
-        // clamp [0, 255] + truncate == saturating convert of floor(v)
-        uint32_t lo = 0, hi = 0;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            lo = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + x]), x, lo);
-            hi = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 + x]), x, hi);
-        }
-        *reinterpret_cast<uint2 *>(dst + y * pitch) = make_uint2(lo, hi);
-    }
+    for (int y = 0; y < 8; ++y) *reinterpret_cast<uint2 *>(dst + y * pitch) = make_uint2(pk[2 * y], pk[2 * y + 1]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -361,16 +354,12 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 dma_strip(s, lane, pl == 0 ? 2 : 0);
                 float g[64];
                 idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                {
+                    uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
+                    trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
 #pragma unroll
-                for (int y = 0; y < 8; ++y)
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        uint32_t v = 0;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)   // clamp [0, 255] + truncate == saturating convert of floor(v)
-                            v = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 * d + i]), i, v);
-                        stash[pl][(2 * y + d) % (INTHREAD ? 16 : 1)] = v;
-                    }
+                    for (int i = 0; i < 16; ++i) stash[pl][i % (INTHREAD ? 16 : 1)] = pk[i];
+                }
 #pragma unroll
                 for (int i = 0; i < (INTHREAD ? 16 : 1); ++i) asm volatile("" : "+v"(stash[pl][i]));
                 __builtin_amdgcn_sched_barrier(0);
@@ -388,15 +377,10 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 float g[64];
                 idct_block(w, sqw[wave][1 + pl], 128.5f, g);
                 uint32_t *dst = sc + pl * PLANE + 8 * r * PITCH + 1 + 2 * c;
+                uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
+                trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
 #pragma unroll
-                for (int y = 0; y < 8; ++y)
-#pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        uint32_t v = 0;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[8 * y + 4 * d + i]), i, v);
-                        dst[y * PITCH + d] = v;
-                    }
+                for (int y = 0; y < 8; ++y) { dst[y * PITCH] = pk[2 * y]; dst[y * PITCH + 1] = pk[2 * y + 1]; }
             }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -409,13 +393,15 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 float g[64];
                 idct_block(w, sqw[wave][1 + pl], 128.5f, g);
                 const bool exists = side ? 16 * sxi + 16 < (a.pw_c >> 3) : sxi > 0;
+                float edge[8];
+                uint32_t e[8];
+#pragma unroll
+                for (int y = 0; y < 8; ++y) edge[y] = side ? g[8 * y] : g[8 * y + 7];
+                trunc_bytes8(edge, e);
                 if (lane < 8 && exists) {
                     uint32_t *dst = sc + pl * PLANE + 8 * r * PITCH + (side ? PITCH - 1 : 0);
 #pragma unroll
-                    for (int y = 0; y < 8; ++y) {
-                        const uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(floorf(side ? g[8 * y] : g[8 * y + 7]), 0, 0u);
-                        dst[y * PITCH] = v * 0x01010101u;
-                    }
+                    for (int y = 0; y < 8; ++y) dst[y * PITCH] = e[y] * 0x01010101u;
                 }
             }
             // plane edges: the reference clamps the sample index to the padded plane (decode.swift:4245)
@@ -632,8 +618,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         };
         // colour of pixel row y of the work-item's block from its luma samples and the row's chroma values; packed as 24 bytes
         auto colour_row = [&](int y, const float (&cv)[2][8], uint32_t (&d)[6]) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) d[j] = 0;
+            float c[24];
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
                 const float yy = yv[8 * y + x];
@@ -641,23 +626,13 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 if constexpr (MODE == 1) {
                     if constexpr (CHROMA) {
                         const float pb = cv[0][x], pr = cv[1][x];
-                        // jpeg.swift:441-453, op for op (the 0.0 * c terms are exact no-ops).
-                        // v_cvt_pk_u8_f32 rounds to nearest-even and saturates; the reference
-                        // clamps and TRUNCATES.  G is floored first.  For R and B the bias
-                        // kTruncBias = -0.5 + 2^-10 added to y turns round-to-nearest into
-                        // truncation for EVERY (y, c) in [0,255] x [-128,127]: the products
-                        // 1.402 c / 1.772 c never come closer than 0.004 to an integer
-                        // (verified exhaustively by tests/test_colour_rounding.py).
-                        // Nor do they come close enough for the rounding of the product to
-                        // matter, so R and B take one FMA each (same test, fused variant).
-                        const float yb = yy + kTruncBias;
-                        c0 = __builtin_fmaf(1.40200f, pr, yb);
-                        // G: floor(fma(m_cr, cr, fma(m_cb, cb, y))) equals the reference's
-                        // trunc((y + m_cb cb) + m_cr cr) for every (y, cb, cr) -- all 2^24
-                        // triples checked in tests/test_colour_rounding.py (the other fused
-                        // association is NOT exact).
-                        c1 = floorf(__builtin_fmaf(-0.71414f, pr, __builtin_fmaf(-0.34414f, pb, yy)));
-                        c2 = __builtin_fmaf(1.77200f, pb, yb);
+                        // jpeg.swift:441-453: x = (y + m_cb cb) + m_cr cr (the 0.0 * c terms are exact no-ops), clamped and
+                        // TRUNCATED -- the pack below.  One FMA for R and B, two for G in this association (the other one is
+                        // NOT exact): after the truncation every one of the 2^16 / 2^24 input combinations gives the
+                        // reference's byte (tests/test_colour_rounding.py enumerates them).
+                        c0 = __builtin_fmaf(1.40200f, pr, yy);
+                        c1 = __builtin_fmaf(-0.71414f, pr, __builtin_fmaf(-0.34414f, pb, yy));
+                        c2 = __builtin_fmaf(1.77200f, pb, yy);
                     } else {
                         c0 = c1 = c2 = yy;  // cb = cr = 128: every matrix term is +-0
                     }
@@ -666,11 +641,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                     c1 = CHROMA ? cv[0][x] : 128.0f;
                     c2 = CHROMA ? cv[1][x] : 128.0f;
                 }
-                // saturating convert of an integer-valued float == clamp [0, 255] + truncate
-                d[(3 * x + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c0, (3 * x + 0) & 3, d[(3 * x + 0) >> 2]);
-                d[(3 * x + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c1, (3 * x + 1) & 3, d[(3 * x + 1) >> 2]);
-                d[(3 * x + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c2, (3 * x + 2) & 3, d[(3 * x + 2) >> 2]);
+                c[3 * x + 0] = c0; c[3 * x + 1] = c1; c[3 * x + 2] = c2;
             }
+            trunc_pack24(c, d);   // clamp [0, 255] + truncate (fused_common.hpp)
         };
         // the row's traffic: store the PREVIOUS row's chunks (their LDS read was issued a row ago; prev < 0: there is none),
         // stage this row (LDS ops of one wave execute in order) and read it back as chunks

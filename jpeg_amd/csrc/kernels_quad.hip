@@ -6,19 +6,19 @@
 //
 // Work decomposition.  One 8 x 8 block per work-item (both IDCT passes and both transposes of decode.swift:3971-4099 are
 // register renames).  A STRIP is BX x BY luma blocks with BX * BY = 64 -- 32 x 2 (256 x 16 px) or 16 x 4 (128 x 32 px) --
-// and one wave's unit of work.  The bilinear chroma filter couples every pixel row to the chroma sample row above / below
-// (decode.swift:4243-4257), so QS vertically adjacent strips form a STACK that the QS waves of a workgroup decode
-// together (4 strips of 32 x 2, or 2 strips of 16 x 4: 256 x 64 / 128 x 64 px), sharing ONE chroma tile in LDS:
-//   - chroma pass: a wave transforms the 32 chroma blocks under its own strip, its share of the blocks whose edge sample
-//     row lies above / below the stack, and the neighbour blocks left / right of its rows (56-60 work-items busy), and
-//     writes the samples as bytes into the tile;
-//   - luma pass: dequantise + IDCT of the strip's 64 luma blocks;
-//   - pixel rows: upsample from the tile (centred 2x: weights 1/4, 3/4), colour matrix, pack, store whole 16-byte chunks
-//     of contiguous row segments through a small LDS staging row.
+// and one wave's unit of luma work.  The bilinear chroma filter couples every pixel row to the chroma sample row above /
+// below (decode.swift:4243-4257), so four vertically adjacent strips form a STACK (256 x 64 / 128 x 128 px) that the four
+// waves of a workgroup decode together, sharing ONE chroma tile in LDS.  Per trip a wave runs
+//   - its ROLE of the chroma pass: the stack's chroma blocks are dealt to the waves by kind -- two waves transform the 128
+//     blocks under the stack (64 each), one the blocks above / below it (only one sample row of each is wanted: a third
+//     of a block's arithmetic), one the neighbour blocks left / right (only the touching column: two thirds) -- and
+//     writes its samples as bytes into the tile; the roles swap between the wave pairs every trip;
+//   - the luma pass: dequantise + IDCT of its strip's 64 luma blocks;
+//   - eight pixel rows: upsample from the tile (centred 2x: weights 1/4, 3/4), colour matrix, pack, store whole 16-byte
+//     chunks of contiguous row segments through a small LDS staging row.
 // Between the waves of a stack there is no barrier, only two monotonic LDS counters: a wave ARRIVES ("my samples are in
-// the tile") right after its chroma pass and checks the counter a luma transform and six pixel rows later, before the two
-// pixel rows that read another wave's samples (rows are processed in the order 1..6, 0, 7); the second counter keeps the
-// tile from being overwritten while a neighbour still reads it.
+// the tile") right after its chroma role and checks the counter a luma transform later, before its first pixel row; the
+// second counter keeps the tile from being overwritten while anyone still reads it.
 // Coefficients arrive by LDS-DMA (global_load_lds_dwordx4) one phase ahead, into the wave's 8 KiB buffer: the luma blocks
 // during the chroma transform, the NEXT stack's chroma blocks during the luma transform and the pixel rows.
 //
@@ -28,7 +28,10 @@
 // predicated stores, the reference's index clamps repaired in the tile), so any image size takes this kernel.
 //
 // Development switches (never defined in the product build): JA_PHASE_PROFILE, JA_X_NOSYNC, JA_X_NOCIDCT, JA_X_NOIDCT,
-// JA_X_NOSTORE, JA_X_STAGGER=<cycles>.
+// JA_X_NOSTORE, JA_X_STAGGER=<cycles>.  (Round 3 also measured: the DMA instructions paced over the pixel rows or
+// interleaved with the transform's columns, several priority schemes, progress feedback between the workgroups of a CU,
+// one chroma pass per strip instead of the roles -- profiles/r03_ab_*.txt; those variants are in git history or under
+// tools/exp_patches/, not in this file.)
 #pragma clang fp contract(off)
 
 #include "dct.hpp"
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         {
             // ---- the chroma pass, by role.  Three complete code paths with nothing merged behind them: with a common
             //      tail LLVM keeps the values of several transforms alive across the branches and spills.  clamp [0, 255]
-            //      + truncate == saturating convert of floor(v).  Before its samples go into the tile a wave checks that
+            //      + truncate == the saturating convert under round-toward-zero (trunc_pack*, fused_common.hpp).  Before its samples go into the tile a wave checks that
             //      everyone has read the previous trip's: the others signalled "done" two pixel rows before the end of
             //      their previous strip, more than a transform ago -- this rarely waits. ----
             const int role = role_of(trip);
@@ -281,13 +284,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 idct_block(w, sqw[qp][1 + pl], 128.5f, g);
 #endif
                 uint32_t pk[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    uint32_t d = 0;
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) d = __builtin_amdgcn_cvt_pk_u8_f32(floorf(g[4 * i + x]), x, d);
-                    pk[i] = d;
-                }
+                trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pk[i]));
                 JA_PHASE(2)
@@ -305,10 +302,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 const bool below = lane >= 2 * CBW;
                 float r[8];
                 idct_block_edge_row(w, sqw[qp][1 + pl], 128.5f, !below, r);
-                uint32_t p0 = 0, p1 = 0;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) { p0 = __builtin_amdgcn_cvt_pk_u8_f32(floorf(r[x]), x, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(floorf(r[4 + x]), x, p1); }
-                asm volatile("" : "+v"(p0), "+v"(p1));
+                uint32_t p01[2];
+                trunc_pack8(r, p01);
+                const uint32_t p0 = p01[0], p1 = p01[1];
                 JA_PHASE(2)
                 lds_wait_ge_seen(done, (uint32_t)(QS * trip), done_seen);
                 JA_PHASE(3)
@@ -321,8 +317,14 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 float c0[8], c7[8];
                 idct_block_edge_cols(w, sqw[qp][1 + pl], 128.5f, c0, c7);
                 uint32_t e[8];   // the edge sample of each row, replicated
+                {
+                    float edge[8];
 #pragma unroll
-                for (int y = 0; y < 8; ++y) e[y] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(side ? c0[y] : c7[y]), 0, 0u) * 0x01010101u;
+                    for (int y = 0; y < 8; ++y) edge[y] = side ? c0[y] : c7[y];
+                    trunc_bytes8(edge, e);
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) e[y] *= 0x01010101u;
+                }
 #pragma unroll
                 for (int y = 0; y < 8; ++y) asm volatile("" : "+v"(e[y]));
                 JA_PHASE(2)
@@ -499,28 +501,25 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                     for (int x = 0; x < 8; ++x) { hw[pl][0][x] = hw[pl][1][x]; hw[pl][1][x] = hw[pl][2][x]; }
                 }
             }
-            uint32_t d[6] = {0, 0, 0, 0, 0, 0};
+            uint32_t d[6];
+            {
+                float c[24];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const float yy = yv[8 * y + x];
-                float c0, c1, c2;
-                if constexpr (MODE == 1) {
-                    const float pb = cv[0][x], pr = cv[1][x];
-                    // jpeg.swift:441-453.  v_cvt_pk_u8_f32 rounds to nearest-even and saturates; the reference clamps and
-                    // TRUNCATES.  R, B: kTruncBias added to y turns round-to-nearest into truncation for every (y, c), one
-                    // FMA each; G: floor(fma(m_cr, cr, fma(m_cb, cb, y))).  Every input triple is enumerated in
-                    // tests/test_colour_rounding.py.
-                    const float yb = yy + kTruncBias;
-                    c0 = __builtin_fmaf(1.40200f, pr, yb);
-                    c1 = floorf(__builtin_fmaf(-0.71414f, pr, __builtin_fmaf(-0.34414f, pb, yy)));
-                    c2 = __builtin_fmaf(1.77200f, pb, yb);
-                } else {
-                    c0 = yy; c1 = cv[0][x]; c2 = cv[1][x];
+                for (int x = 0; x < 8; ++x) {
+                    const float yy = yv[8 * y + x];
+                    if constexpr (MODE == 1) {
+                        const float pb = cv[0][x], pr = cv[1][x];
+                        // jpeg.swift:441-453: x = (y + m_cb cb) + m_cr cr, clamped and TRUNCATED -- the pack below.  One FMA
+                        // for R and B, two for G: after the truncation every one of the 2^16 / 2^24 input combinations gives
+                        // the reference's byte (tests/test_colour_rounding.py enumerates them).
+                        c[3 * x + 0] = __builtin_fmaf(1.40200f, pr, yy);
+                        c[3 * x + 1] = __builtin_fmaf(-0.71414f, pr, __builtin_fmaf(-0.34414f, pb, yy));
+                        c[3 * x + 2] = __builtin_fmaf(1.77200f, pb, yy);
+                    } else {
+                        c[3 * x + 0] = yy; c[3 * x + 1] = cv[0][x]; c[3 * x + 2] = cv[1][x];
+                    }
                 }
-                // saturating convert of an integer-valued float == clamp [0, 255] + truncate
-                d[(3 * x + 0) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c0, (3 * x + 0) & 3, d[(3 * x + 0) >> 2]);
-                d[(3 * x + 1) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c1, (3 * x + 1) & 3, d[(3 * x + 1) >> 2]);
-                d[(3 * x + 2) >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(c2, (3 * x + 2) & 3, d[(3 * x + 2) >> 2]);
+                trunc_pack24(c, d);   // clamp [0, 255] + truncate
             }
             __builtin_amdgcn_sched_barrier(0);
             // the row's traffic: the previous row's stores, this row's staging, the request for the next patch row

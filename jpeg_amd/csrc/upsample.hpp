@@ -8,10 +8,6 @@
 
 namespace jpeg_amd {
 
-// trunc(clamp(x, 0, 255)) == saturating round-to-nearest(x + kTruncBias) for the R and B
-// channel values x = y + m c (see k_luma_fused and tests/test_colour_rounding.py)
-constexpr float kTruncBias = -0.5f + 0.0009765625f;
-
 template <int N>
 __device__ __forceinline__ float ubyte(uint32_t v)
 {

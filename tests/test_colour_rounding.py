@@ -1,30 +1,27 @@
-"""Exhaustive CPU proof of the rounding shortcut used by k_luma_fused (kernels_fused.hip).
+"""Exhaustive CPU proof of the colour stage's shortcuts in the fused decode kernels (kernels_quad.hip, kernels_fused.hip).
 
-The reference clamps to [0, 255] and TRUNCATES the colour-matrix result (jpeg.swift:343-354,
-441-453).  gfx950's v_cvt_pk_u8_f32 rounds to nearest-even and saturates (tools/probe_isa.hip).
-For the R and B channels, x = y + m*c with y in [0, 255], c in [-128, 127] integers, the kernel
-evaluates sat_rne((y + kTruncBias) + m*c) with kTruncBias = -0.5 + 2^-10 instead of
-trunc(clamp(y + m*c)).  This test checks EVERY (y, c) pair for both channels in binary32, and
-documents that the same shortcut is NOT valid for G (two products), which the kernel floors.
+The reference clamps the colour-matrix result to [0, 255] and TRUNCATES (jpeg.swift:343-354, 441-453).  The kernels pack with
+v_cvt_pk_u8_f32 under round-toward-zero (trunc_pack*, fused_common.hpp; tools/probe_cvt_round.hip shows that the instruction
+follows the wave's rounding mode): saturate + truncate, the same conversion for every float.  What remains to prove is the
+arithmetic in front of it: the kernels use one FMA for R and B and two for G where the reference rounds every product and
+every sum.  These tests check EVERY input combination in binary32.
 """
 import numpy as np
 
 f32 = np.float32
-BIAS = f32(-0.5) + f32(2.0 ** -10)      # kTruncBias in kernels_fused.hip
 
 
 def _ref(x):   # clamp then truncate toward zero
     return np.clip(x, f32(0), f32(255)).astype(np.int32)
 
 
-def _hw(z):    # v_cvt_pk_u8_f32: round to nearest even, saturate
-    return np.clip(np.rint(z), 0, 255).astype(np.int32)
+def _hw(z):    # v_cvt_pk_u8_f32 under round-toward-zero: truncate, saturate
+    return np.clip(np.trunc(z), 0, 255).astype(np.int32)
 
 
-def test_bias_is_exactly_representable_and_exact_when_added():
-    y = np.arange(256, dtype=f32)
-    assert f32(BIAS) == BIAS
-    assert np.all((y + BIAS).astype(np.float64) == y.astype(np.float64) + np.float64(BIAS))
+def test_the_truncating_convert_is_the_references_conversion():
+    x = np.concatenate([np.linspace(-300, 600, 90001, dtype=f32), np.arange(-2, 258, dtype=f32), np.nextafter(np.arange(0, 257, dtype=f32), f32(-1e9))])
+    assert np.array_equal(_ref(x), _hw(x))
 
 
 def test_red_and_blue_every_input():
@@ -33,34 +30,11 @@ def test_red_and_blue_every_input():
     for m in (f32(1.40200), f32(1.77200)):
         p = (m * c).astype(f32)                       # one rounding, as in the reference
         want = _ref((y + p).astype(f32))
-        got = _hw(((y + BIAS).astype(f32) + p).astype(f32))
-        assert np.array_equal(want, got)
-
-
-def test_red_and_blue_fused_multiply_add_every_input():
-    """The kernel evaluates sat_rne(fma(m, c, y + kTruncBias)): one rounding of the exact
-    m*c + (y + bias).  float64 holds that sum exactly (24-bit x 8-bit product, 19-bit addend)."""
-    y = np.arange(256, dtype=f32)[:, None]
-    c = np.arange(-128, 128, dtype=f32)[None, :]
-    yb = (y + BIAS).astype(f32)
-    for m in (f32(1.40200), f32(1.77200)):
-        want = _ref((y + (m * c).astype(f32)).astype(f32))
-        exact = np.float64(m) * c.astype(np.float64) + yb.astype(np.float64)
-        assert np.all(exact - yb.astype(np.float64) == np.float64(m) * c.astype(np.float64))   # no f64 rounding
-        got = _hw(exact.astype(f32))
-        assert np.array_equal(want, got)
-
-
-def test_green_needs_the_floor():
-    y = np.arange(256, dtype=f32)[:, None, None]
-    pb = np.arange(-128, 128, dtype=f32)[None, :, None]
-    pr = np.arange(-128, 128, dtype=f32)[None, None, :]
-    q1 = (f32(-0.34414) * pb).astype(f32)
-    q2 = (f32(-0.71414) * pr).astype(f32)
-    x = ((y + q1).astype(f32) + q2).astype(f32)
-    z = (((y + BIAS).astype(f32) + q1).astype(f32) + q2).astype(f32)
-    assert (_ref(x) != _hw(z)).any()                  # the shortcut would be wrong here ...
-    assert np.array_equal(_ref(x), _hw(np.floor(x)))  # ... floor + saturating convert is exact
+        # the kernel: fma(m, c, y), one rounding of the exact m*c + y.  float64 holds that sum exactly (24-bit x 8-bit
+        # product, 8-bit addend)
+        exact = np.float64(m) * c.astype(np.float64) + y.astype(np.float64)
+        assert np.all(exact - y.astype(np.float64) == np.float64(m) * c.astype(np.float64))   # no f64 rounding
+        assert np.array_equal(want, _hw(exact.astype(f32)))
 
 
 def _fma(p, q, r):
@@ -76,9 +50,9 @@ def test_green_two_fused_multiply_adds_every_input():
     a, b = f32(-0.34414), f32(-0.71414)
     x = ((y + (a * pb).astype(f32)).astype(f32) + (b * pr).astype(f32)).astype(f32)
     want = _ref(x)
-    got = _hw(np.floor(_fma(b, pr, _fma(a, pb, y + 0 * pb))))
+    got = _hw(_fma(b, pr, _fma(a, pb, y + 0 * pb)))
     assert np.array_equal(want, got)                  # the kernel's form: exact on all 2^24 triples
-    other = _hw(np.floor(_fma(a, pb, _fma(b, pr, y + 0 * pr))))
+    other = _hw(_fma(a, pb, _fma(b, pr, y + 0 * pr)))
     assert (other != want).any()                      # the other association is not
 
 

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """A/B of two builds of the library on the 4:2:0 decode: alternating child processes (JPEG_AMD_LIBRARY), several
-rounds, median and minimum per build and case.  usage (GPU box): tools/ab_lib.py <exp-name> [rounds]
+rounds, median and minimum per build and case.  usage (GPU box): tools/ab_lib.py <exp-name>[,<exp-name>...] [rounds]
 (<exp-name>: tools/exp/libjpeg_amd_<exp-name>.so from tools/build_exp.sh; the other side is the product build)"""
 import sys, os, subprocess, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("200", "8192", "8192", "1"), ("30", "1920", "1080", "512"), ("300", "4096", "4096", "1"), ("100", "1920", "1080", "64")]
 name = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-libs = {name: os.path.join(ROOT, "tools", "exp", f"libjpeg_amd_{name}.so"), "product": ""}
+libs = {n: os.path.join(ROOT, "tools", "exp", f"libjpeg_amd_{n}.so") for n in name.split(",")}
+libs["product"] = ""
 res = {}
 for r in range(rounds):
     for case in CASES:

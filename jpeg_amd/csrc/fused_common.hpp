@@ -56,6 +56,31 @@ __device__ __forceinline__ void lds_dma16_s_keep(uint64_t sbase, uint32_t voff, 
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" JA_KEEP_HINT ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
 }
+// A RUN of N consecutive 1 KiB pieces (a contiguous source, a contiguous destination): the instruction's offset field moves
+// the global source AND the LDS destination (tools/probe_dma_offset.hip), so the whole run needs one M0 write and one
+// scalar base.  Piece j takes the per-lane offset v0 (even j) or v1 (odd j): the source-side swizzle alternates.
+template <int N, bool NT>
+__device__ __forceinline__ void lds_dma16_run(uint64_t sbase, uint32_t v0, uint32_t v1, uint32_t lds)
+{
+    static_assert(N == 2 || N == 4, "runs of 2 or 4 KiB");
+    if constexpr (N == 2) {
+        if constexpr (NT)
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt\n\tglobal_load_lds_dwordx4 %2, %0 offset:1024 nt"
+                         ::"s"(sbase), "v"(v0), "v"(v1), "s"(lds) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" JA_KEEP_HINT "\n\tglobal_load_lds_dwordx4 %2, %0 offset:1024" JA_KEEP_HINT
+                         ::"s"(sbase), "v"(v0), "v"(v1), "s"(lds) : "memory");
+    } else {
+        if constexpr (NT)
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 nt\n\tglobal_load_lds_dwordx4 %2, %0 offset:1024 nt\n\t"
+                         "global_load_lds_dwordx4 %1, %0 offset:2048 nt\n\tglobal_load_lds_dwordx4 %2, %0 offset:3072 nt"
+                         ::"s"(sbase), "v"(v0), "v"(v1), "s"(lds) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" JA_KEEP_HINT "\n\tglobal_load_lds_dwordx4 %2, %0 offset:1024" JA_KEEP_HINT "\n\t"
+                         "global_load_lds_dwordx4 %1, %0 offset:2048" JA_KEEP_HINT "\n\tglobal_load_lds_dwordx4 %2, %0 offset:3072" JA_KEEP_HINT
+                         ::"s"(sbase), "v"(v0), "v"(v1), "s"(lds) : "memory");
+    }
+}
 // 4 bytes per lane: lane l's dword lands at LDS byte address lds + 4 l.
 __device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32_t lds)
 {

@@ -187,16 +187,52 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         lds_dma16(reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
     };
 
+    // a whole pass at once.  Interior strips / stacks whose blocks lie in runs of 2 or 4 KiB take one M0 write and one scalar
+    // base per run (lds_dma16_run); everything else goes piece by piece.
+    auto dma_luma = [&](int img, int syi, int sxi, int lane) {
+        if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {   // interior strip (wave-uniform): BY runs of BX blocks
+            const uint32_t l3 = lane >> 3;
+            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+            const uint64_t base = reinterpret_cast<uint64_t>(a.coef[0] + img * a.coef_stride[0]);
+#pragma unroll
+            for (int r = 0; r < BY; ++r) {
+                const uint32_t blk0 = (uint32_t)(BY * syi + r) * a.ux + sxi * BX;
+                lds_dma16_run<BX / 8, true>(base + ((uint64_t)blk0 << 7), ve, ve ^ 64u, coef_lds + r * (BX * 128));
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma_luma_one(i, img, syi, sxi, lane);
+    };
+    auto dma_chroma = [&](int img, int syi, int sxi, int lane, int role) {
+        if constexpr (BX == 32) {
+            if (role < 3 && CBW * sxi + CBW <= a.uxc) {   // wave-uniform: four runs of sixteen neighbouring blocks
+                const uint32_t l3 = lane >> 3;
+                const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+                const int top = syi - qp;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {   // pieces 2 u, 2 u + 1 of dma_chroma_one
+                    const int pl = u & 1;
+                    int row = role < 2 ? top + 2 * role + (u >> 1) : ((u >> 1) ? CBR * (top + QS) : CBR * top - 1);
+                    row = min(max(row, 0), a.uyc - 1);   // missing rows: fetched, not used
+                    const uint64_t sb = reinterpret_cast<uint64_t>(a.coef[1 + pl] + img * a.coef_stride[1 + pl]) +
+                                        ((uint64_t)((uint32_t)row * (uint32_t)a.uxc + (uint32_t)(CBW * sxi)) << 7);
+                    lds_dma16_run<2, false>(sb, ve, ve ^ 64u, coef_lds + 2048 * u);
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, img, syi, sxi, lane, role);
+    };
+
 #ifdef JA_X_STAGGER   // experiment: the three workgroups of a CU start a third of a strip apart
     for (int d = (int)(blockIdx.x / 256u) * (JA_X_STAGGER); d > 0; d -= 64 * 100) __builtin_amdgcn_s_sleep(100);
 #endif
     if (trips <= 0) return;
-    {
-        int img, syi, sxi;
-        locate(stack_of(0), img, syi, sxi);
-#pragma unroll
-        for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, img, syi, sxi, lane0, role_of(0));
-    }
+    int c_img, c_syi, c_sxi;   // the current trip's stack (located once, a trip ahead)
+    locate(stack_of(0), c_img, c_syi, c_sxi);
+    dma_chroma(c_img, c_syi, c_sxi, lane0, role_of(0));
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
     JA_PHASE_DECL
@@ -207,8 +243,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int lbx = lane & (BX - 1), seg = (int)((unsigned)lane / BX);
-        int img, syi, sxi;
-        locate(stack_of(trip), img, syi, sxi);
+        const int img = c_img, syi = c_syi, sxi = c_sxi;
         // a strip below the image (the last stack of an image may be short): the wave still plays its role in the chroma
         // pass and keeps the counters, but has no luma blocks and no pixels
         const bool phantom = syi >= strips_y;
@@ -247,10 +282,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         const uint32_t done_seen = lds_peek(done);   // checked after the transform; read here so that the check costs no round trip
         // w holds the chroma pass's block; the luma blocks of the strip follow it into the buffer
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!phantom) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dma_luma_one(i, img, syi, sxi, lane);
-        }
+        if (!phantom) dma_luma(img, syi, sxi, lane);
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(1)
 
@@ -352,12 +384,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         }
         const bool more = trip + 1 < trips;
         int n_img = 0, n_syi = 0, n_sxi = 0;
-        if (more) locate(stack_of(trip + 1), n_img, n_syi, n_sxi);
+        if (more) { locate(stack_of(trip + 1), n_img, n_syi, n_sxi); c_img = n_img; c_syi = n_syi; c_sxi = n_sxi; }
         if (phantom) {   // nothing to decode: the next pass's blocks, both counters, next trip
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, n_img, n_syi, n_sxi, lane, role_of(trip + 1));
-            }
+            if (more) dma_chroma(n_img, n_syi, n_sxi, lane, role_of(trip + 1));
             lds_arrive(done, lane);
             stores_behind_dma = 0;
             continue;
@@ -372,10 +401,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         //      burst costs; one or two per pixel row change nothing: profiles/r03_ab_*dma*.txt.) ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         JA_PHASE(12)
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, n_img, n_syi, n_sxi, lane, role_of(trip + 1));
-        }
+        if (more) dma_chroma(n_img, n_syi, n_sxi, lane, role_of(trip + 1));
         const uint32_t ready_seen = lds_peek(ready);
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(13)
@@ -478,8 +504,14 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
             if (a.W < 0)
 #endif
             if (FAST && full) {
-                put(rowp + voff0, pv0, j0);
-                if (lane < 32) put(rowp + voff1, pv1, j1);
+                // chunk `lane` from every lane, chunk 64 + lane from lanes 0 .. 31: scalar row base + 32-bit lane offset, and
+                // the second store under a narrowed EXEC instead of a branch (this path runs with all 64 lanes active)
+                const u32x4_t q0 = {pv0.x, pv0.y, pv0.z, pv0.w}, q1 = {pv1.x, pv1.y, pv1.z, pv1.w};
+                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\t"
+                             "s_mov_b64 exec, %5\n\t"
+                             "global_store_dwordx4 %3, %4, %2 nt\n\t"
+                             "s_mov_b64 exec, -1"
+                             ::"v"(voff0), "v"(q0), "s"(rowp), "v"(voff1), "v"(q1), "s"(0xffffffffull) : "memory");
             } else {
                 if (col0 && 8 * BY * syi + 8 * sg0 + yy < a.H) put(rowp + voff0, pv0, j0);
                 if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);

@@ -19,7 +19,7 @@
         unsigned s = 0; float l = 0;                                                                     \
         const float *lp = lds + (threadIdx.x & 63);                                                      \
         for (int i = 0; i < iters; ++i) {                                                                \
-            asm volatile(STR : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+s"(s) : "v"(a)); \
+            asm volatile(STR : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+s"(s) : "v"(a) : "scc"); \
             EXTRA                                                                                        \
         }                                                                                                \
         out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + l + (float)s;     \
@@ -37,9 +37,10 @@ int main()
     struct { const char *name; kfn fn; double valu_per_iter; } ks[] = {
         {"v_add_f32 (8 chains)", k_add, 64}, {"v_floor_f32 (8 chains)", k_floor, 64},
         {"v_add_f32 + s_add_u32 alternating", k_add_salu, 64}, {"64 v_add_f32 + 1 ds_read_b32 waited for", k_add_lds, 64}};
-    const int iters = 2000;
+    const int iters = 500;
     printf("%-42s", "waves per SIMD:");
     for (int w = 1; w <= 8; ++w) printf(" %7d", w);
+    fflush(stdout);
     printf("   (VALU instructions per SIMD per 1000 cycles at 2.4 GHz; 500 = one per 2 cycles)\n");
     for (auto &k : ks) {
         printf("%-42s", k.name);

@@ -220,11 +220,10 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                     const uint32_t l3 = lane >> 3;
                     const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int16_t *cbase = a.ccoef[i >> 2] + img * a.ccoef_stride[i >> 2];
-                        const uint32_t blk0 = (uint32_t)(2 * syi + ((i >> 1) & 1)) * uxc + 16 * sxi + 8 * (i & 1);
-                        const uint64_t sb = reinterpret_cast<uint64_t>(cbase) + ((uint64_t)blk0 << 7);
-                        lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+                    for (int u = 0; u < 4; ++u) {   // four runs of sixteen neighbouring blocks: one M0 write and one base each
+                        const int16_t *cbase = a.ccoef[u >> 1] + img * a.ccoef_stride[u >> 1];
+                        const uint32_t blk0 = (uint32_t)(2 * syi + (u & 1)) * uxc + 16 * sxi;
+                        lds_dma16_run<2, true>(reinterpret_cast<uint64_t>(cbase) + ((uint64_t)blk0 << 7), ve, ve ^ 64u, coef_lds + 2048 * u);
                     }
                     return;
                 }
@@ -255,10 +254,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             const uint32_t l3 = lane >> 3;
             const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);  // even i; odd i: chunk ^ 4
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t blk0 = (uint32_t)(BY * syi + i / (BX / 8)) * a.ux + sxi * BX + 8 * (i % (BX / 8));
-                const uint64_t sb = reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7);
-                lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
+            for (int r = 0; r < BY; ++r) {   // BY runs of BX neighbouring blocks: one M0 write and one base each (fused_common.hpp)
+                const uint32_t blk0 = (uint32_t)(BY * syi + r) * a.ux + sxi * BX;
+                lds_dma16_run<BX / 8, true>(reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7), ve, ve ^ 64u, coef_lds + r * (BX * 128));
             }
             return;
         }
@@ -609,8 +607,14 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             if (a.W < 0)
 #endif
             if (FAST && full) {
-                put(rowp + voff0, pv0, j0);
-                if (lane < 32) put(rowp + voff1, pv1, j1);
+                // chunk `lane` from every lane, chunk 64 + lane from lanes 0 .. 31: scalar row base + 32-bit lane offset, and
+                // the second store under a narrowed EXEC instead of a branch (this path runs with all 64 lanes active)
+                const u32x4_t q0 = {pv0.x, pv0.y, pv0.z, pv0.w}, q1 = {pv1.x, pv1.y, pv1.z, pv1.w};
+                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\t"
+                             "s_mov_b64 exec, %5\n\t"
+                             "global_store_dwordx4 %3, %4, %2 nt\n\t"
+                             "s_mov_b64 exec, -1"
+                             ::"v"(voff0), "v"(q0), "s"(rowp), "v"(voff1), "v"(q1), "s"(0xffffffffull) : "memory");
             } else {
                 if (col0 && 8 * BY * syi + 8 * sg0 + yy < a.H) put(rowp + voff0, pv0, j0);
                 if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);

@@ -59,7 +59,8 @@ struct QuadArgs {
     int W, H;
     uint8_t *out;
     size_t out_stride;
-    int tiles_x;                   // strips per strip row
+    int tiles_x;                   // strip columns this launch walks ...
+    int sx0;                       // ... starting at this one (units of BX blocks)
     int stacks_per_image;          // tiles_x * stack rows
     int nstacks;                   // of the whole call
 };
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         uint32_t rem, col;
         img = (int)fd_spi.div((uint32_t)q, rem);
         syi = QS * (int)fd_tx.div(rem, col) + qp;
-        sxi = (int)col;
+        sxi = (int)col + a.sx0;
     };
     const int trips = (a.nstacks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // stacks this workgroup walks
     const int strips_y = (a.uy + BY - 1) / BY;
@@ -625,15 +626,28 @@ bool quad_decode_supported(const jpeg_amd_layout &L)
     return L.units_x[1] == L.units_x[2] && L.units_y[1] == L.units_y[2];
 }
 
-// Strip shape: 32 x 2 blocks unless 16 x 4 covers the plane with fewer strips (a half-empty strip costs as much as a full
-// one: 1920 x 1080 is 7.5 x 68 strips of 32 x 2 but exactly 15 x 34 of 16 x 4).
-int quad_strip_width(int ux, int uy)
+// How a plane is cut into strip columns.  A stack costs a workgroup the same whether its strips are full, half empty
+// (a partial last column) or phantom (a short last stack), so the cut that needs the fewest stacks wins: 32 x 2 strips
+// throughout, 16 x 4 strips throughout, or -- for batches, where a second launch is free -- 32 x 2 strips for the whole
+// columns and ONE column of 16 x 4 strips for a remainder of at most 16 blocks (1920 x 1080: 7 columns x 17 stacks + 1 x 9
+// = 128 stacks per image for 126.6 stacks' worth of blocks, where 15 columns of 16 x 4 strips need 135 and 8 of 32 x 2 136).
+struct QuadCut { int parts; int bx[2], sx0[2], cols[2]; };
+static long quad_stacks(int cols, int uy, int by) { return (long)cols * (((uy + by - 1) / by + 3) / 4); }
+QuadCut quad_cut(int ux, int uy, long n_images, long resident)
 {
 #ifdef JA_X_FORCE_BX
-    return JA_X_FORCE_BX;
+    return QuadCut{1, {JA_X_FORCE_BX, 0}, {0, 0}, {(ux + JA_X_FORCE_BX - 1) / JA_X_FORCE_BX, 0}};
 #endif
-    const long wide = (long)((ux + 31) / 32) * ((uy + 1) / 2), narrow = (long)((ux + 15) / 16) * ((uy + 3) / 4);
-    return narrow < wide ? 16 : 32;
+    const long wide = quad_stacks((ux + 31) / 32, uy, 2), narrow = quad_stacks((ux + 15) / 16, uy, 4);
+    QuadCut best = narrow < wide ? QuadCut{1, {16, 0}, {0, 0}, {(ux + 15) / 16, 0}} : QuadCut{1, {32, 0}, {0, 0}, {(ux + 31) / 32, 0}};
+    const int whole = ux / 32, rest = ux - 32 * whole;
+    if (whole > 0 && rest > 0 && rest <= 16) {
+        const long mixed = quad_stacks(whole, uy, 2) + quad_stacks(1, uy, 4);
+        // worth a second launch only when the call is many trips long (the narrow column's launch is at least one trip)
+        if (mixed < std::min(wide, narrow) && n_images * std::min(wide, narrow) >= 16 * resident)
+            best = QuadCut{2, {32, 16}, {0, 2 * whole}, {whole, 1}};
+    }
+    return best;
 }
 
 hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const PlaneSet &coef, QuantaRef q,
@@ -650,23 +664,24 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
     a.uxc = L.units_x[1]; a.uyc = L.units_y[1];
     a.W = L.width; a.H = L.height;
     a.out = d_pixels; a.out_stride = pixel_stride;
-    const int bx = quad_strip_width(a.ux, a.uy), by = 64 / bx, qs = 4;
-    a.tiles_x = (a.ux + bx - 1) / bx;
-    const int strips_y = (a.uy + by - 1) / by, stacks_y = (strips_y + qs - 1) / qs;
-    a.stacks_per_image = a.tiles_x * stacks_y;
-    const long nstacks = (long)a.stacks_per_image * n_images;
-    if (nstacks == 0) return hipSuccess;
-    if (nstacks > 0x3fffffffL) return hipErrorInvalidValue;
-    a.nstacks = (int)nstacks;
+    if (n_images == 0 || a.ux == 0 || a.uy == 0) return hipSuccess;
     const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-#define JA_Q(BX_)                                                                                                  \
-    {                                                                                                              \
-        if (fast) return rgb ? launch_quad<1, BX_, true>(stream, a) : launch_quad<0, BX_, true>(stream, a);        \
-        return rgb ? launch_quad<1, BX_, false>(stream, a) : launch_quad<0, BX_, false>(stream, a);                \
+    const QuadCut cut = quad_cut(a.ux, a.uy, n_images, quad_resident_workgroups<1, 32, true>());
+    for (int part = 0; part < cut.parts; ++part) {
+        const int bx = cut.bx[part];
+        a.tiles_x = cut.cols[part]; a.sx0 = cut.sx0[part];
+        a.stacks_per_image = (int)quad_stacks(a.tiles_x, a.uy, 64 / bx);
+        const long nstacks = (long)a.stacks_per_image * n_images;
+        if (nstacks > 0x3fffffffL) return hipErrorInvalidValue;
+        a.nstacks = (int)nstacks;
+        hipError_t e;
+        if (bx == 16) e = fast ? (rgb ? launch_quad<1, 16, true>(stream, a) : launch_quad<0, 16, true>(stream, a))
+                               : (rgb ? launch_quad<1, 16, false>(stream, a) : launch_quad<0, 16, false>(stream, a));
+        else e = fast ? (rgb ? launch_quad<1, 32, true>(stream, a) : launch_quad<0, 32, true>(stream, a))
+                      : (rgb ? launch_quad<1, 32, false>(stream, a) : launch_quad<0, 32, false>(stream, a));
+        if (e != hipSuccess) return e;
     }
-    if (bx == 16) JA_Q(16)
-    JA_Q(32)
-#undef JA_Q
+    return hipSuccess;
 }
 
 }  // namespace jpeg_amd

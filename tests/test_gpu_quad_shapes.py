@@ -74,3 +74,34 @@ def test_420_batches_of_edge_shapes(env, size, n):
     for i in range(n):
         _, rect = O.decode(batch[i], [quanta[0], quanta[1], quanta[1]], [(2, 2), (1, 1), (1, 1)], size, threads=8)
         assert (got[i] == O.unpack_rgb8(rect, 3, threads=8).reshape(-1)).all(), i
+
+
+@pytest.mark.parametrize("size,n", [((384, 272), 1400), ((1920, 1080), 93)])
+def test_420_large_batches_take_the_mixed_column_cut(env, size, n):
+    """Batches that are many trips long are cut into 32 x 2 strips for the whole columns plus ONE column of 16 x 4 strips
+    for a remainder of at most 16 blocks (two launches, quad_cut in kernels_quad.hip): 384 x 272 is 1 + 1 columns (8 stacks
+    per image instead of 9), 1920 x 1080 7 + 1 (128 instead of 135).  The seam between the two launches runs through
+    the middle of the image: a sample of the batch against the oracle."""
+    J, O, ctx = env
+    import torch
+    from jpeg_amd import _lib
+    import ctypes as C
+    rng = np.random.default_rng(17)
+    quanta = [rng.integers(1, 30, 64).astype(np.uint16) for _ in range(2)]
+    layout = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    units = layout.units(size)
+    W, H = size
+    dev = ctx.torch_device
+    pool = [np.clip(rng.laplace(0, 40, (8, uy, ux, 64)), -1000, 1000).astype(np.int16) for ux, uy in units]   # 8 distinct images
+    host = [p[np.arange(n) % 8] for p in pool]
+    d_planes = [torch.from_numpy(h).to(dev) for h in host]
+    d_q = torch.from_numpy(np.stack(quanta).view(np.int16)).to(dev)
+    out = torch.zeros((n, W * H * 3), dtype=torch.uint8, device=dev)
+    L = layout.c_layout(size, units, [0, 1, 1])
+    strides = _lib.size_array([64 * a * b for a, b in units])
+    st = _lib.lib().jpeg_amd_decode_batch(ctx.handle, C.byref(L), n, _lib.ptr_array([p.data_ptr() for p in d_planes]), strides,
+                                          d_q.data_ptr(), 0, 2, 0, _lib.COLOR_RGB8, out.data_ptr(), W * H * 3)
+    assert st == 0
+    for i in sorted({0, 1, n // 3, n // 2, n - 2, n - 1}):
+        _, rect = O.decode([h[i] for h in host], [quanta[0], quanta[1], quanta[1]], [(2, 2), (1, 1), (1, 1)], size, threads=8)
+        assert (out[i].cpu().numpy() == O.unpack_rgb8(rect, 3, threads=8).reshape(-1)).all(), i

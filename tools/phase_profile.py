@@ -34,7 +34,14 @@ names = ["wait chroma coef DMA", "chroma block read + luma DMA issue", "chroma I
          "tile write + arrive", "patch row requests", "luma IDCT", "hrow prologue + geometry",
          "pixel rows 1-5", "wait for the stack's tile (RAW)", "halo repair, rows 6, 0, 7, last stores", "luma DMA wait (vmcnt 0)",
          "luma block read + lgkmcnt(0)", "next chroma DMA issue"]
-nstrips = 16384 if N == 1 and W == 8192 and H == 8192 else 4 * N * (-(-units[0][0] // 16) * -(-(-(-units[0][1] // 4)) // 4) if -(-units[0][0] // 16) * -(-units[0][1] // 4) < -(-units[0][0] // 32) * -(-units[0][1] // 2) else -(-units[0][0] // 32) * -(-(-(-units[0][1] // 2)) // 4))
+def _stacks(cols, uy, by): return cols * ((-(-uy // by) + 3) // 4)
+def _cut(ux, uy, n):   # quad_cut in kernels_quad.hip
+    wide, narrow = _stacks(-(-ux // 32), uy, 2), _stacks(-(-ux // 16), uy, 4)
+    whole, rest = ux // 32, ux % 32
+    if whole and 0 < rest <= 16 and _stacks(whole, uy, 2) + _stacks(1, uy, 4) < min(wide, narrow) and n * min(wide, narrow) >= 16 * 768:
+        return _stacks(whole, uy, 2) + _stacks(1, uy, 4)
+    return min(wide, narrow)
+nstrips = 4 * N * _cut(units[0][0], units[0][1], N)   # strip slots of the call (the LAST launch's waves are what the profile arrays hold)
 tot = buf[:, :14].sum(axis=1).astype(np.float64)
 print(f"step {ms*1e3:.1f} us; per-wave total cycles mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
 for i, n in enumerate(names):

@@ -300,6 +300,11 @@ int jpeg_amd_timer_end(jpeg_amd_ctx *ctx, float *elapsed_ms)
     JA_TRY(bind(ctx));
     if (!elapsed_ms) return JPEG_AMD_EINVAL;
     JA_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    // poll instead of sleeping on the event: a blocked host thread takes tens of microseconds to wake up, which a caller
+    // that brackets a short timed region with its own clock would charge to the region
+    hipError_t q;
+    while ((q = hipEventQuery(ctx->ev_end)) == hipErrorNotReady) {}
+    JA_HIP(ctx, q);
     JA_HIP(ctx, hipEventSynchronize(ctx->ev_end));
     JA_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
     return JPEG_AMD_OK;

@@ -1,17 +1,17 @@
-// kernels_fused.hip -- fused Spectral -> pixels fast path for the built-in 8-bit formats.
+// kernels_fused.hip -- fused Spectral -> pixels fast path for the built-in 8-bit formats other than 4:2:0.
 //
 // Replaces idct() -> interleaved(cosite: false) -> unpack(as:) (decode.swift:4154, 4182,
-// 4294) for ycc8 images whose luma has the full sampling factor and whose chroma planes are
-// subsampled 1x or 2x per axis (4:4:4, 4:2:2, 4:4:0, 4:2:0), and for y8 images, without
-// materialising Planar / Rectangular in HBM.  Two launches (one for y8, 4:4:4 and 4:2:2, where
-// the work-items transform the Cb and Cr blocks under their strip themselves):
+// 4294) for y8 images and for ycc8 images whose luma has the full sampling factor and whose chroma planes are
+// subsampled 1x or 2x on ONE axis at most (4:4:4, 4:2:2, 4:4:0), without materialising Planar / Rectangular -- or
+// anything else -- in HBM: one launch of k_luma_fused.  (4:2:0 couples strips vertically AND horizontally: k_quad420,
+// kernels_quad.hip.)
 //
-//   k_chroma_idct   Cb and Cr: dequantise + IDCT, clamp, store as uint8 planes (a scratch of
-//                   0.5 B/px for 4:2:0 -- small enough to stay in L2 / Infinity Cache).
-//   k_luma_fused    one luma 8x8 block per work-item: dequantise + IDCT in registers; the
-//                   workgroup stages its chroma tile (+1 sample halo, clamped to the padded
-//                   plane like decode.swift:4245-4246) in LDS; bilinear upsample, YCbCr->RGB,
-//                   pack and store 8 rows x 24 B.
+//   k_luma_fused    one luma 8x8 block per work-item: dequantise + IDCT in registers; the wave transforms the chroma
+//                   blocks under its strip itself -- 4:4:4: every work-item its own Cb and Cr block; 4:2:2 and 4:4:0:
+//                   one pass for the 64 blocks under the strip and one for the neighbour blocks whose edge column
+//                   (4:2:2) or edge row (4:4:0) the filter reaches into -- and keeps their samples as bytes in a
+//                   wave-private LDS tile (+1 sample halo, clamped to the padded plane like decode.swift:4245-4246);
+//                   bilinear upsample, YCbCr->RGB, pack and store 8 rows x 24 B.
 //
 // Exactness of the upsample shortcut.  For centred 2x upsampling the reference's weights are
 // t in {1/4, 3/4} (decode.swift:4231-4251), so u00*(1-t) + u01*t etc. are sums of small
@@ -22,13 +22,9 @@
 // 4250) because 0.25*c + 0.75*c == c exactly.  Everything that rounds (dequantise, IDCT,
 // colour matrix) is evaluated op-for-op as in dct.hpp / the reference.
 //
-// Development switches (never defined in the product build; tools/build_exp.sh makes A/B builds,
-// DESIGN.md section 6 quotes the measurements): JA_PHASE_PROFILE (per-phase cycle counters,
-// tools/phase_profile.py), JA_X_NOIDCT / JA_X_NOCOLOR / JA_X_NOSTORE / JA_X_NOCTILE (the kernel without its transform /
-// without its upsampling and colour arithmetic / without its stores / without the chroma tile copy: tools/ablate.sh),
-// JA_X_SKIPK1 / JA_X_SKIPK2 (one launch of the pair only, tools/probe_overlap.py),
-// JA_X_NO_IN420 / JA_X_FORCE_IN420 (4:2:0 chroma in the strip walk never / whenever the strips are wide),
-// JA_X_IN420_NT (its neighbour fetches with the `nt` hint: 8 % slower, they are re-used out of L2).
+// Development switches (never defined in the product build; tools/build_exp.sh makes A/B builds):
+// JA_X_NOIDCT / JA_X_NOCOLOR / JA_X_NOSTORE (the kernel without its transform / without its upsampling and colour
+// arithmetic / without its stores: tools/ablate.sh), JA_X_NOPRIO.
 #pragma clang fp contract(off)
 
 #include "dct.hpp"
@@ -47,63 +43,12 @@ namespace {
 // images whose width leaves the last 32-block strip half empty (1920 px = 7.5 strips of 32)
 
 // ---------------------------------------------------------------------------------------
-// K1: chroma planes -> uint8 samples.  blockIdx.z selects the plane (same geometry).
-// ---------------------------------------------------------------------------------------
-struct ChromaArgs {
-    const int16_t *coef[2];
-    size_t coef_stride[2];
-    uint8_t *out[2];
-    size_t out_stride;
-    const uint16_t *quanta;
-    size_t quanta_stride;
-    int qi[2];
-    int ux, first_block, end_block;   // this launch transforms blocks [first_block, end_block) of every image
-};
-
-__global__ __launch_bounds__(kThreads) void k_chroma_idct(ChromaArgs a)
-{
-    __shared__ float sq[64];
-    const int img = blockIdx.y, pl = blockIdx.z;
-    // the table's quantum is requested first, the block's coefficients right behind it: one memory latency at the head of
-    // the workgroup instead of two (table, barrier, then the coefficient loads)
-    const int qk = threadIdx.x & 7, qh = (threadIdx.x >> 3) & 7;
-    uint16_t qraw = 1;
-    if (threadIdx.x < 64) qraw = a.quanta[img * a.quanta_stride + 64 * a.qi[pl] + zigzag_of(qk, qh)];
-    const int b = a.first_block + blockIdx.x * kThreads + threadIdx.x;
-    const bool mine = b < a.end_block;
-    const int bc = mine ? b : a.end_block - 1;   // work-items past the range re-read the last block and store nothing
-    const int by = bc / a.ux, bx = bc - by * a.ux;
-
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.coef[pl] + img * a.coef_stride[pl] + (size_t)64 * bc);
-    uint32_t w[32];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint4 v = src[i];
-        w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-    }
-    if (threadIdx.x < 64) sq[threadIdx.x] = modulate_entry(qk, qh, 0.125f, qraw);
-    __syncthreads();
-    if (!mine) return;
-    float g[64];
-    idct_block(w, sq, 128.5f, g);  // level = 2^(P-1) + 0.5, P = 8
-
-    const size_t pitch = (size_t)8 * a.ux;
-    uint8_t *dst = a.out[pl] + img * a.out_stride + (size_t)8 * by * pitch + 8 * bx;
-    uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
-    trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
-#pragma unroll
-    for (int y = 0; y < 8; ++y) *reinterpret_cast<uint2 *>(dst + y * pitch) = make_uint2(pk[2 * y], pk[2 * y + 1]);
-}
-
-// ---------------------------------------------------------------------------------------
-// K2: luma IDCT + chroma upsample + colour + store
+// luma IDCT + chroma IDCT + upsample + colour + store
 // ---------------------------------------------------------------------------------------
 struct LumaArgs {
     const int16_t *coef;
     size_t coef_stride;
-    const uint8_t *cb, *cr;  // uint8 planes [ph_c][pw_c] (unused for grey and for 4:4:4)
-    size_t c_stride;
-    const int16_t *ccoef[2]; // 4:4:4: the chroma coefficient planes themselves (same geometry as luma)
+    const int16_t *ccoef[2]; // the chroma coefficient planes
     size_t ccoef_stride[2];
     int cqi[2];
     const uint16_t *quanta;
@@ -156,27 +101,28 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     constexpr int NW = kThreads / 64;                    // waves per workgroup
     constexpr int CW = BX * 8 / SX;                      // chroma samples per strip row
     constexpr int CR = BY * 8 / SY;                      // chroma rows under a strip
-    // halo bytes per side.  The tiles that k_chroma_idct's planes are copied into by LDS-DMA carry 16: a tile row is
-    // then a whole number of 16-byte chunks and the copy takes 4-5 DMA instructions of 16 B per lane instead of
-    // 20-36 of 4 B (an LDS-DMA instruction costs 60-185 cycles to ISSUE whatever it moves: the 20 row transfers of
-    // a 32 x 2 strip were 15 % of the strip's wall time).  The tiles the strip fills itself keep 4.
-    constexpr int HX = SX == 2 ? ((SY == 1 && BX == 32) ? 4 : 16) : 0;
+    constexpr int HX = SX == 2 ? 4 : 0;                  // halo bytes per side
     constexpr int HY = SY == 2 ? 1 : 0;
     constexpr int PITCH = (CW + 2 * HX) / 4;             // dwords per LDS row
     constexpr int ROWS = CR + 2 * HY;
-    // 4:4:4: no k_chroma_idct launch and no chroma round trip through HBM -- every work-item
-    // transforms the Cb and Cr blocks that lie under its luma block itself (same geometry), parks
-    // their samples as bytes in LDS ([dword][lane], like k_encode_fused) and then does the luma block
+    // 4:4:4: every work-item transforms the Cb and Cr blocks that lie under its luma block itself (same geometry),
+    // parks their samples as bytes in 32 registers and then does the luma block
     constexpr bool INTHREAD = CHROMA && SX == 1 && SY == 1;
     constexpr int PLANE = (CHROMA && !INTHREAD) ? ROWS * PITCH : 1;   // dwords per plane of the tile
     constexpr int SEG_DW = BX * 6;                       // one pixel row of one block row: 24 B per block
     constexpr int CPS = SEG_DW / 4;                      // 16-byte chunks per such segment
     // 4:2:2 (wide strips): the 16 x 2 chroma blocks per plane under a strip are exactly one block per
     // work-item for both planes together; a second, nearly empty pass transforms the 8 neighbour
-    // blocks that supply the one-sample halo left and right.  No k_chroma_idct launch, no chroma
-    // round trip through HBM (it was 134 of 604 MB at 8192 x 8192).
+    // blocks that supply the one-sample halo left and right.  No chroma intermediate in HBM (round 2; it was
+    // 134 of 604 MB at 8192 x 8192).
     constexpr bool IN422 = CHROMA && SX == 2 && SY == 1 && BX == 32;
-    constexpr bool INSTRIP = INTHREAD || IN422;   // no k_chroma_idct in front of this kernel
+    // 4:4:0 (narrow strips, 16 x 4 luma blocks): the 16 x 2 chroma blocks per plane under a strip are again one block per
+    // work-item, and the 2 x 16 x 2 blocks of the block rows above and below -- of which only the nearest sample row is
+    // wanted (idct_block_edge_row: a third of a block's arithmetic) -- one more.  No chroma intermediate in HBM (round 3:
+    // a first launch used to write the Cb / Cr samples as bytes, 134 of 604 MB at 8192 x 8192).
+    constexpr bool IN440 = CHROMA && SX == 1 && SY == 2 && BX == 16;
+    static_assert(!(CHROMA && SX == 1 && SY == 2) || IN440, "4:4:0 is written for the 16 x 4 strip");
+    constexpr bool INSTRIP = INTHREAD || IN422 || IN440;   // the kernel transforms its chroma blocks itself
     constexpr int NTAB = INSTRIP ? 3 : 1;
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
@@ -190,7 +136,6 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     // LDS byte address of the wave's coefficient buffer (low 32 bits of the flat shared address)
     const uint32_t coef_lds = lds_address(coef_w);
     uint32_t *sc = scw[wave];
-    const uint32_t sc_lds = lds_address(sc);
     float *sq = sqw[wave][0];
 
     // strip s -> image, strip row (BY block rows), strip column (BX blocks)
@@ -213,7 +158,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         if constexpr (INTHREAD) {
             if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
         }
-        if constexpr (IN422) {
+        if constexpr (IN422 || IN440) {
             const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
             if (which == 1) {   // block b of the buffer: plane b >> 5, row (b >> 4) & 1, column b & 15
                 if (16 * sxi + 16 <= uxc && 2 * syi + 2 <= uyc) {
@@ -235,6 +180,30 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                     const uint32_t blk = (bx < uxc && by < uyc) ? (uint32_t)by * uxc + bx : 0u;
                     const int c = (lane & 7) ^ ((b >> 1) & 7);
                     lds_dma16(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+                }
+                return;
+            }
+            if (which == 3) {   // 4:4:0 halo: block b of the buffer: below b >> 5, plane (b >> 4) & 1, column b & 15
+                const int rows[2] = {min(max(2 * syi - 1, 0), uyc - 1), min(2 * syi + 2, uyc - 1)};   // missing rows: fetched, not used
+                if (16 * sxi + 16 <= uxc) {
+                    const uint32_t l3 = lane >> 3;
+                    const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int16_t *cbase = a.ccoef[u & 1] + img * a.ccoef_stride[u & 1];
+                        const uint32_t blk0 = (uint32_t)rows[u >> 1] * uxc + 16 * sxi;
+                        lds_dma16_run<2, false>(reinterpret_cast<uint64_t>(cbase) + ((uint64_t)blk0 << 7), ve, ve ^ 64u, coef_lds + 2048 * u);
+                    }
+                    return;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int16_t *cbase = a.ccoef[(i >> 1) & 1] + img * a.ccoef_stride[(i >> 1) & 1];
+                    const int b = 8 * i + (lane >> 3);
+                    const int bx = 16 * sxi + (b & 15);
+                    const uint32_t blk = bx < uxc ? (uint32_t)rows[i >> 2] * uxc + bx : 0u;
+                    const int c = (lane & 7) ^ ((b >> 1) & 7);
+                    lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
                 }
                 return;
             }
@@ -421,61 +390,56 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             read_block();
         }
 
-        // ---- chroma samples under the strip (+ halo): one LDS-DMA per row straight into this
-        //      wave's LDS tile (lane = dword column); they land during the IDCT.  Row index
-        //      clamped by the scalar unit, column index clamped per lane to the padded plane;
-        //      the replication a clamped COLUMN needs is patched in LDS on edge strips only. ----
-        const int cx0 = sxi * CW, cy0 = syi * CR;
-        const int pwd = a.pw_c >> 2;
-#ifdef JA_X_NOCTILE   // experiment: no copy of the chroma samples under the strip (what do those small reads cost?)
-        if constexpr (false) {
-#else
-        if constexpr (CHROMA && !INSTRIP) {
-#endif
-            // rows of a narrow tile are packed RPI to a transfer (the LDS image is lane-linear and the
-            // tile rows are contiguous): 12 transfers instead of 36 for a 16 x 4 strip of 4:2:0
-            constexpr int RPI = (ROWS % (64 / PITCH) == 0) ? 64 / PITCH : 1;
-            constexpr int CHUNKS = PITCH / 4;                 // 16-byte chunks per tile row
-            constexpr int SLOTS = 2 * ROWS * CHUNKS;          // both planes
-            if (PITCH % 4 == 0 && (a.pw_c & 15) == 0 && a.pw_c >= 16) {
-                // 16 bytes per lane: slot u = 64 i + lane is chunk u % CHUNKS of tile row u / CHUNKS (rows of both planes
-                // back to back); its LDS address is 16 u -- the tile rows are contiguous.  Chunks are clamped to the plane
-                // as a whole (the plane is a whole number of chunks wide here); what a clamped chunk holds is repaired below.
+        if constexpr (IN440) {
+            const int uyc = a.ph_c >> 3;
+            // pass 1: the strip's own chroma blocks (lane: plane, block row, block column) -> tile rows 1 .. 16
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_strip(s, lane, 3);
+            {
+                const int pl = lane >> 5, r = (lane >> 4) & 1, c = lane & 15;
+                float g[64];
+                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                uint32_t *dst = sc + pl * PLANE + (HY + 8 * r) * PITCH + 2 * c;
+                uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
+                trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
 #pragma unroll
-                for (int i = 0; i < (SLOTS + 63) / 64; ++i) {
-                    const int u = 64 * i + lane;
-                    const int r = (int)((unsigned)u / CHUNKS), ch = u - r * CHUNKS;
-                    const int pl = r >= ROWS ? 1 : 0;
-                    const int gy = min(max(cy0 - HY + r - pl * ROWS, 0), a.ph_c - 1);
-                    const int gx = min(max(cx0 - HX + 16 * ch, 0), a.pw_c - 16);
-                    const uint8_t *g = (pl ? a.cr : a.cb) + img * a.c_stride + ((size_t)gy * a.pw_c + gx);
-                    if (u < SLOTS) lds_dma16_keep(g, sc_lds + 1024 * i);
-                }
-            } else if constexpr (RPI == 1) {
-                const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + lane, 0), pwd - 1);
-                if (lane < PITCH) {
-#pragma unroll
-                    for (int vr = 0; vr < 2 * ROWS; ++vr) {
-                        const int pl = vr >= ROWS ? 1 : 0;
-                        const int gy = min(max(cy0 - HY + vr - pl * ROWS, 0), a.ph_c - 1);
-                        const uint64_t rowbase = reinterpret_cast<uint64_t>((pl ? a.cr : a.cb) + img * a.c_stride) +
-                                                 (uint64_t)((uint32_t)gy * (uint32_t)a.pw_c);
-                        lds_dma4_s(rowbase, coff, sc_lds + 4 * PITCH * vr);
-                    }
-                }
-            } else {
-                const int rin = (int)((unsigned)lane / PITCH), col = lane - rin * PITCH;
-                const uint32_t coff = 4u * (uint32_t)min(max((cx0 - HX) / 4 + col, 0), pwd - 1);
-                if (lane < RPI * PITCH) {
-#pragma unroll
-                    for (int k = 0; k < 2 * ROWS / RPI; ++k) {
-                        const int pl = k * RPI >= ROWS ? 1 : 0;   // ROWS % RPI == 0: a transfer never straddles the planes
-                        const int gy = min(max(cy0 - HY + k * RPI - pl * ROWS + rin, 0), a.ph_c - 1);
-                        const uint64_t planebase = reinterpret_cast<uint64_t>((pl ? a.cr : a.cb) + img * a.c_stride);
-                        lds_dma4_s(planebase, (uint32_t)gy * (uint32_t)a.pw_c + coff, sc_lds + 4 * PITCH * RPI * k);
-                    }
+                for (int y = 0; y < 8; ++y) { dst[y * PITCH] = pk[2 * y]; dst[y * PITCH + 1] = pk[2 * y + 1]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_block();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_strip(s, lane, 0);
+            // pass 2: the block rows above and below (lane: below, plane, column): the last / first sample row of each
+            // -> tile rows 0 and 17
+            {
+                const bool below = lane >= 32;
+                const int pl = (lane >> 4) & 1, c = lane & 15;
+                float r8[8];
+                idct_block_edge_row(w, sqw[wave][1 + pl], 128.5f, !below, r8);
+                uint32_t p01[2];
+                trunc_pack8(r8, p01);
+                if (below ? 2 * syi + 2 < uyc : syi > 0) {
+                    uint32_t *dst = sc + pl * PLANE + (below ? HY + CR : 0) * PITCH + 2 * c;
+                    dst[0] = p01[0]; dst[1] = p01[1];
                 }
             }
+            // the plane's top and bottom: the reference clamps the sample row (decode.swift:4246) -- a missing row is the
+            // nearest own row.  Only this wave reads its tile.
+            {
+                const int rows_avail = a.ph_c - syi * CR;   // sample rows of the plane from the first one under this strip
+                auto copy_row = [&](int dstr, int srcr) {
+                    for (int d = lane; d < 2 * PITCH; d += 64) {
+                        uint32_t *col = sc + (d >= PITCH ? PLANE + d - PITCH : d);
+                        col[dstr * PITCH] = col[srcr * PITCH];
+                    }
+                };
+                if (syi == 0) copy_row(0, 1);
+                if (rows_avail > 0 && rows_avail <= CR) copy_row(rows_avail + 1, rows_avail);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_block();
         }
 
         // ---- luma: dequantise + IDCT, clamp + truncate (decode.swift:4121-4122), kept as
@@ -497,23 +461,6 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(yv[i]));
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- the chroma rows have landed (they are the only VM operations in flight) ----
-        if constexpr (CHROMA && !INSTRIP) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int first_bad = pwd - (cx0 - HX) / 4;          // first tile dword past the plane (>= HX / 4 + 1)
-            if ((HX > 0 && sxi == 0) || first_bad < PITCH) {     // wave-uniform: edge strips only
-                // the reference clamps the SAMPLE index to the padded plane (decode.swift:4245): whatever the clamped
-                // transfers put left of the first / right of the last sample is replaced by that sample
-                if (lane < 2 * ROWS) {
-                    uint32_t *row = sc + lane * PITCH;
-                    if (HX > 0 && sxi == 0) row[HX / 4 - 1] = (row[HX / 4] & 0xffu) * 0x01010101u;
-                    if (first_bad < PITCH) {
-                        const uint32_t last = (row[first_bad - 1] >> 24) * 0x01010101u;
-                        for (int c = first_bad; c < PITCH; ++c) row[c] = last;
-                    }
-                }
-            }
-        }
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
         if (valid(k + nwaves)) dma_strip(strip_at(k + nwaves), lane, INSTRIP ? 1 : 0);
@@ -710,7 +657,6 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
 }
 
 
-inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
 
 // Persistent grid = what is resident at once: workgroups per CU (LDS- and VGPR-bound, differs per
 // instantiation: 3 for grey, 2 for the variants with a chroma tile or stash) x CUs.
@@ -739,7 +685,7 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
 #define JA_K(SX_, SY_, CH_) go(k_luma_fused<SX_, SY_, MODE, CH_, FAST, BX>, resident_workgroups<SX_, SY_, MODE, CH_, FAST, BX>());
     if (!chroma) JA_K(1, 1, false)
     else if (sx == 2 && sy == 1) { if constexpr (BX == 32) JA_K(2, 1, true) }
-    else if (sx == 1 && sy == 2) { if constexpr (BX == 32) JA_K(1, 2, true) }
+    else if (sx == 1 && sy == 2) { if constexpr (BX == 16) JA_K(1, 2, true) }
     else JA_K(1, 1, true)
 #undef JA_K
     return hipGetLastError();
@@ -750,7 +696,7 @@ hipError_t launch_luma(hipStream_t stream, int wgs, const LumaArgs &a, int sx, i
 // tiles of a 16 x 4 strip would need 64 row transfers.
 inline int strip_width(int ux, int uy, int sx, int sy)
 {
-    if (sx != sy) return 32;   // (the 4:2:2 in-thread chroma passes are written for the wide strip)
+    if (sx != sy) return sx == 2 ? 32 : 16;   // the in-strip chroma passes: 4:2:2 is written for the wide strip, 4:4:0 for the narrow one
     const long wide = (long)((ux + 31) / 32) * ((uy + 1) / 2), narrow = (long)((ux + 15) / 16) * ((uy + 3) / 4);
     return narrow < wide ? 16 : 32;
 }
@@ -774,14 +720,9 @@ bool fused_decode_supported(const jpeg_amd_layout &L, bool cosited)
     return true;
 }
 
-// Only 4:4:0 keeps an intermediate (its Cb / Cr samples as bytes, written by k_chroma_idct and read by k_luma_fused):
-// grey, 4:4:4 and 4:2:2 transform everything inside k_luma_fused, 4:2:0 inside k_quad420.
-size_t fused_decode_scratch_bytes(const jpeg_amd_layout &L, int n_images)
-{
-    if (L.nplanes == 1 || L.scale_y == 1 || L.scale_x == 2) return 0;
-    const size_t plane = (size_t)64 * L.units_x[1] * L.units_y[1];
-    return 2 * ((plane * n_images + 255) & ~(size_t)255);
-}
+// No layout keeps an intermediate in HBM any more (4:4:0 was the last, round 3): every kernel transforms the chroma blocks
+// it needs itself.
+size_t fused_decode_scratch_bytes(const jpeg_amd_layout &, int) { return 0; }
 
 hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L,
                                const PlaneSet &coef, QuantaRef q, bool rgb, void *scratch,
@@ -790,32 +731,14 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     const bool chroma = L.nplanes == 3;
     if (chroma && L.scale_x == 2 && L.scale_y == 2)   // 4:2:0: the stack walk (kernels_quad.hip), one launch, no intermediate
         return launch_quad_decode(stream, n_images, L, coef, q, rgb, d_pixels, pixel_stride);
-    // 4:4:4: k_luma_fused transforms all three planes itself (no intermediate, no first launch)
-    // 4:2:2 likewise (the chroma blocks under a strip are one per work-item; see IN422)
-    const bool inthread = chroma && L.scale_y == 1;
-    const bool two_launches = chroma && !inthread;   // 4:4:0
+    // 4:4:4, 4:2:2, 4:4:0: k_luma_fused transforms the chroma blocks under (and around) its strips itself
     LumaArgs la{};
-    ChromaArgs ca{};
-    const size_t cplane = chroma ? (size_t)64 * L.units_x[1] * L.units_y[1] : 0;
-    if (inthread) {
+    if (chroma) {
         for (int i = 0; i < 2; ++i) {
             la.ccoef[i] = static_cast<const int16_t *>(coef.ptr[1 + i]);
             la.ccoef_stride[i] = coef.stride[1 + i];
             la.cqi[i] = L.qi[1 + i];
         }
-        la.pw_c = 8 * L.units_x[1]; la.ph_c = 8 * L.units_y[1];
-    } else if (chroma) {
-        const size_t half = (cplane * n_images + 255) & ~(size_t)255;
-        for (int i = 0; i < 2; ++i) {
-            ca.coef[i] = static_cast<const int16_t *>(coef.ptr[1 + i]);
-            ca.coef_stride[i] = coef.stride[1 + i];
-            ca.out[i] = static_cast<uint8_t *>(scratch) + i * half;
-            ca.qi[i] = L.qi[1 + i];
-        }
-        ca.out_stride = cplane;
-        ca.quanta = q.d_quanta; ca.quanta_stride = q.image_stride;
-        ca.ux = L.units_x[1]; ca.first_block = 0; ca.end_block = L.units_x[1] * L.units_y[1];
-        la.cb = ca.out[0]; la.cr = ca.out[1]; la.c_stride = cplane;
         la.pw_c = 8 * L.units_x[1]; la.ph_c = 8 * L.units_y[1];
     }
     la.coef = static_cast<const int16_t *>(coef.ptr[0]);
@@ -834,11 +757,6 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     if (la.total_tiles == 0) return hipSuccess;
     const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-    if (two_launches) {
-        hipLaunchKernelGGL(k_chroma_idct, dim3(blocks_for(ca.end_block), n_images, 2), dim3(kThreads), 0, stream, ca);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
     // grid == resident capacity (launch_luma clamps).  (Sizing it so that every wave gets the same number of
     // strips -- fewer waves, no thin last round -- measured 4 % slower; 2 instead of 3 workgroups per CU 3.5 %.)
     const int wgs = (la.total_tiles + 3) / 4;

@@ -221,10 +221,9 @@ def test_planes_beyond_4GiB_are_addressed_in_64_bits(env):
             assert torch.equal(c, w[64 * ux * m0 * f:64 * ux * m1 * f]), (m0, m1)
 
 
-def test_single_image_and_batch_take_different_420_paths_and_agree(env):
-    """One 2048 x 1024 4:2:0 image goes through the single-launch kernel (chroma transformed inside
-    the strip walk), a batch of the same geometry through k_chroma_idct + k_luma_fused: same pixels,
-    both equal to the oracle, for both colour targets' RGB case and at the image's edges."""
+def test_single_image_and_batch_of_420_agree(env):
+    """One 2048 x 1024 4:2:0 image and a batch of the same geometry (the stack numbering runs through the batch,
+    k_quad420): same pixels, both equal to the oracle."""
     e = env
     size, n = (2048, 1024), 3
     planes = e["synth"].natural_planes_torch(e["layout"].units(size), n, e["ctx"].torch_device, 5)

@@ -50,3 +50,5 @@ run("4:2:0 -> RGB", c420, "ycc8", _lib.COLOR_RGB8)
 run("4:2:0 -> YCC", c420, "ycc8", _lib.COLOR_YCC8)
 run("4:2:2 -> RGB", c422, "ycc8", _lib.COLOR_RGB8)
 run("4:4:4 -> RGB", c444, "ycc8", _lib.COLOR_RGB8)
+c440 = {1: J.Component((1, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)}
+run("4:4:0 -> RGB", c440, "ycc8", _lib.COLOR_RGB8)

@@ -99,11 +99,12 @@ __device__ __forceinline__ uint32_t lds_address(T *p)
 // The waiting side polls with plain LDS reads; what it reads from the tile after the poll has succeeded is issued, and
 // therefore performed, after the read that saw the counter.  Relaxed atomics + compiler barriers on purpose: a release /
 // acquire at workgroup scope would make hipcc wait with vmcnt(0) -- for the coefficient DMA in flight and for the pixel stores.
-__device__ __forceinline__ void lds_arrive(uint32_t *counter, int lane)
+// Call with all 64 lanes active: one lane adds, selected by narrowing EXEC around the ds_add (the compiler's form of
+// "if (lane == 0) atomicAdd" is a dozen instructions: compare, save EXEC, count the active lanes, multiply, restore).
+__device__ __forceinline__ void lds_arrive(uint32_t *counter)
 {
-    asm volatile("" ::: "memory");
-    if (lane == 0) (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)counter;
+    asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(1u) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_peek(uint32_t *counter)
 {

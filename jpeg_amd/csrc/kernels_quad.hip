@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
             }
         }
         // this wave's samples are in the tile: arrive, do not wait yet
-        lds_arrive(ready, lane);
+        lds_arrive(ready);
         JA_PHASE(4)
         {
             const int rem = trips - 1 - trip;   // strips after this one
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         if (more) { locate(stack_of(trip + 1), n_img, n_syi, n_sxi); c_img = n_img; c_syi = n_syi; c_sxi = n_sxi; }
         if (phantom) {   // nothing to decode: the next pass's blocks, both counters, next trip
             if (more) dma_chroma(n_img, n_syi, n_sxi, lane, role_of(trip + 1));
-            lds_arrive(done, lane);
+            lds_arrive(done);
             stores_behind_dma = 0;
             continue;
         }
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 for (int pl = 0; pl < 2; ++pl) hraw(pl, (y >> 1) + 3, rawn[pl]);
                 // after the request for patch row 5 the wave reads nothing more from the tile (the LDS performs the reads
                 // before the add)
-                if (y == 5) lds_arrive(done, lane);
+                if (y == 5) lds_arrive(done);
             }
         }
         __builtin_amdgcn_sched_barrier(0);

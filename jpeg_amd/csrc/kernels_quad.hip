@@ -28,7 +28,7 @@
 // predicated stores, the reference's index clamps repaired in the tile), so any image size takes this kernel.
 //
 // Development switches (never defined in the product build): JA_PHASE_PROFILE, JA_X_NOSYNC, JA_X_NOCIDCT, JA_X_NOIDCT,
-// JA_X_NOSTORE, JA_X_STAGGER=<cycles>.  (Round 3 also measured: the DMA instructions paced over the pixel rows or
+// JA_X_NOSTORE, JA_X_STAGGER=<cycles>, JA_X_GRID_PER_CU=<1 | 2>.  (Round 3 also measured: the DMA instructions paced over the pixel rows or
 // interleaved with the transform's columns, several priority schemes, progress feedback between the workgroups of a CU,
 // one chroma pass per strip instead of the roles -- profiles/r03_ab_*.txt; those variants are in git history or under
 // tools/exp_patches/, not in this file.)
@@ -597,6 +597,9 @@ template <int MODE, int BX, bool FAST>
 hipError_t launch_quad(hipStream_t stream, const QuadArgs &a)
 {
     int cap = quad_resident_workgroups<MODE, BX, FAST>();
+#ifdef JA_X_GRID_PER_CU   // experiment: fewer resident workgroups per CU than fit
+    cap = std::min(cap, (JA_X_GRID_PER_CU) * (cap / 3));
+#endif
 #ifdef JA_PHASE_PROFILE   // development aid: JA_GRID_CAP=256 runs one workgroup per CU (a wave alone on its SIMD)
     if (const char *e = std::getenv("JA_GRID_CAP")) cap = std::min(cap, std::atoi(e));
 #endif

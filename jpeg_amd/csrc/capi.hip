@@ -25,6 +25,7 @@ struct jpeg_amd_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     uint16_t *d_qstage = nullptr;  // ring of staged host tables
+    uint32_t *d_walk = nullptr;    // two dwords, zero between launches: the ticket counters of the 4:2:0 walk (kernels_quad.hip)
     int qslot = 0;
     int last_hip = 0;
     // staging of jpeg_amd_decompress_batch, kept between calls: two pinned host slots (the host
@@ -195,6 +196,8 @@ int jpeg_amd_ctx_create(int device, void *stream, int flags, jpeg_amd_ctx **out)
         }
         if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { status = JPEG_AMD_EHIP; break; }
         if (hipMalloc(reinterpret_cast<void **>(&ctx->d_qstage), kQSlots * kQSlotElems * sizeof(uint16_t)) != hipSuccess) { status = JPEG_AMD_ENOMEM; break; }
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_walk), 256) != hipSuccess) { status = JPEG_AMD_ENOMEM; break; }
+        if (hipMemset(ctx->d_walk, 0, 256) != hipSuccess) { status = JPEG_AMD_EHIP; break; }
     } while (0);
     if (status != JPEG_AMD_OK) {
         jpeg_amd_ctx_destroy(ctx);
@@ -211,6 +214,7 @@ int jpeg_amd_ctx_destroy(jpeg_amd_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_qstage) (void)hipFree(ctx->d_qstage);
+    if (ctx->d_walk) (void)hipFree(ctx->d_walk);
     for (int i = 0; i < 2; ++i) {
         if (ctx->file_pinned[i]) (void)hipHostFree(ctx->file_pinned[i]);
         if (ctx->file_done[i]) (void)hipEventDestroy(ctx->file_done[i]);
@@ -396,9 +400,8 @@ int jpeg_amd_decode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_ima
     if (fused_decode_supported(*L, cosited != 0)) {
         PlaneSet cs{};
         for (int p = 0; p < L->nplanes; ++p) { cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p]; }
-        JA_TRY(ensure_scratch(ctx, fused_decode_scratch_bytes(*L, n_images)));
         JA_HIP(ctx, launch_fused_decode(ctx->stream, n_images, *L, cs, QuantaRef{d_quanta, quanta_stride},
-                                        color == JPEG_AMD_COLOR_RGB8, ctx->scratch, d_pixels, pixel_stride));
+                                        color == JPEG_AMD_COLOR_RGB8, ctx->d_walk, d_pixels, pixel_stride));
         return JPEG_AMD_OK;
     }
 

@@ -722,15 +722,13 @@ bool fused_decode_supported(const jpeg_amd_layout &L, bool cosited)
 
 // No layout keeps an intermediate in HBM any more (4:4:0 was the last, round 3): every kernel transforms the chroma blocks
 // it needs itself.
-size_t fused_decode_scratch_bytes(const jpeg_amd_layout &, int) { return 0; }
-
 hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L,
-                               const PlaneSet &coef, QuantaRef q, bool rgb, void *scratch,
+                               const PlaneSet &coef, QuantaRef q, bool rgb, uint32_t *d_walk_counters,
                                uint8_t *d_pixels, size_t pixel_stride)
 {
     const bool chroma = L.nplanes == 3;
     if (chroma && L.scale_x == 2 && L.scale_y == 2)   // 4:2:0: the stack walk (kernels_quad.hip), one launch, no intermediate
-        return launch_quad_decode(stream, n_images, L, coef, q, rgb, d_pixels, pixel_stride);
+        return launch_quad_decode(stream, n_images, L, coef, q, rgb, d_walk_counters, d_pixels, pixel_stride);
     // 4:4:4, 4:2:2, 4:4:0: k_luma_fused transforms the chroma blocks under (and around) its strips itself
     LumaArgs la{};
     if (chroma) {

@@ -61,6 +61,8 @@ struct QuadArgs {
     size_t out_stride;
     int tiles_x;                   // strip columns this launch walks ...
     int sx0;                       // ... starting at this one (units of BX blocks)
+    uint32_t *tickets;             // dynamic walk (long calls): [0] stacks handed out beyond the first round, [1] workgroups
+                                   // that have finished; nullptr: workgroup b walks stacks b, b + grid, b + 2 grid ...
     int stacks_per_image;          // tiles_x * stack rows
     int nstacks;                   // of the whole call
 };
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
     __shared__ float sqw[NW][3][64];                      // modulated tables: Y, Cb, Cr
     // two monotonic counters.  [0] "ready": a wave has written its samples of this trip into the tile;
     // [1] "done": a wave has read the last sample of this trip.
+    __shared__ uint32_t next_slot[2];                     // dynamic walk: the stack of the next trip (wave 0 publishes it, double-buffered)
     __shared__ uint32_t qsync[2];
 
     const int lane0 = threadIdx.x & 63;
@@ -231,6 +234,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
     for (int d = (int)(blockIdx.x / 256u) * (JA_X_STAGGER); d > 0; d -= 64 * 100) __builtin_amdgcn_s_sleep(100);
 #endif
     if (trips <= 0) return;
+    // The walk.  Static (a.tickets == nullptr): workgroup b takes stacks b, b + grid, ...  Dynamic, for calls that are many
+    // trips long: the first stack is b, every further one a ticket from a global counter -- wave 0 draws it at the top of a
+    // trip and publishes it in LDS before its arrival at "ready", the others pick it up behind their wait for "ready".  A
+    // SIMD issues its oldest ready wave first, so the workgroups a CU received first run faster than the later ones
+    // (512 x 1080p, static: the three generations end at 77 / 87 / 100 % of the call, profiles/r03_ab_generation_priority.txt);
+    // with tickets the fast ones simply walk more stacks and everybody leaves together (-5 %).  Short walks keep the
+    // static order: their last round is better planned than drawn (8192 x 8192, 5.33 trips: +5 % with tickets).
+    const bool dyn = a.tickets != nullptr;
+    int cur = (int)blockIdx.x;
+    const int last_round = a.nstacks - (int)gridDim.x, second_last_round = a.nstacks - 2 * (int)gridDim.x;
     int c_img, c_syi, c_sxi;   // the current trip's stack (located once, a trip ahead)
     locate(stack_of(0), c_img, c_syi, c_sxi);
     dma_chroma(c_img, c_syi, c_sxi, lane0, role_of(0));
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
     int stores_behind_dma = 0;  // wave-uniform
     JA_PHASE_DECL
 
-    for (int trip = 0; trip < trips; ++trip) {
+    for (int trip = 0;; ++trip) {
         // Launder the lane id once per strip: everything below that depends only on the lane is
         // cheap to recompute, but hoisted out of this loop it would pin ~60 VGPRs for good.
         int lane = lane0;
@@ -269,6 +282,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         // "ready" counter a wave runs at the top priority (whoever arrives late is waited for by the others);
         // after it at most at priority 2, by strips left -- laggards catch up and the waves of a SIMD leave together.
         __builtin_amdgcn_s_setprio(3);
+        uint32_t ticket = 0;
+        if (dyn && qp == 0 && lane0 == 0) ticket = __hip_atomic_fetch_add(a.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ONE lane
         uint32_t w[32];
         auto read_block = [&]() {
             const uint4 *cw = reinterpret_cast<const uint4 *>(coef_w) + 8 * lane;
@@ -374,22 +389,31 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 }
             }
         }
-        // this wave's samples are in the tile: arrive, do not wait yet
+        // this wave's samples are in the tile: arrive, do not wait yet.  (Dynamic walk: wave 0 publishes the next trip's stack
+        // BEFORE it arrives -- the LDS performs a wave's operations in order; the atomic was issued a chroma pass ago.)
+        if (dyn && qp == 0 && lane0 == 0) *(volatile uint32_t *)&next_slot[trip & 1] = gridDim.x + ticket;
         lds_arrive(ready);
         JA_PHASE(4)
-        {
-            const int rem = trips - 1 - trip;   // strips after this one
-            if (rem >= 2) __builtin_amdgcn_s_setprio(2);
-            else if (rem == 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-        const bool more = trip + 1 < trips;
-        int n_img = 0, n_syi = 0, n_sxi = 0;
-        if (more) { locate(stack_of(trip + 1), n_img, n_syi, n_sxi); c_img = n_img; c_syi = n_syi; c_sxi = n_sxi; }
+        if (cur < second_last_round) __builtin_amdgcn_s_setprio(2);        // by rounds left after this stack
+        else if (cur < last_round) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        bool more = false;
+        auto take = [&](int next) {   // the stack of the next trip: locate it and request the blocks of its chroma pass
+            more = next < a.nstacks;
+            if (more) {
+                int n_img, n_syi, n_sxi;
+                locate(next, n_img, n_syi, n_sxi); c_img = n_img; c_syi = n_syi; c_sxi = n_sxi;
+                dma_chroma(n_img, n_syi, n_sxi, lane, role_of(trip + 1));
+                cur = next;
+            }
+        };
+        auto drawn = [&]() -> int { return __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&next_slot[trip & 1]); };
         if (phantom) {   // nothing to decode: the next pass's blocks, both counters, next trip
-            if (more) dma_chroma(n_img, n_syi, n_sxi, lane, role_of(trip + 1));
+            if (dyn) { lds_wait_ge(ready, (uint32_t)(QS * (trip + 1))); take(drawn()); }
+            else take(cur + (int)gridDim.x);
             lds_arrive(done);
             stores_behind_dma = 0;
+            if (!more) break;
             continue;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -402,7 +426,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         //      burst costs; one or two per pixel row change nothing: profiles/r03_ab_*dma*.txt.) ----
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         JA_PHASE(12)
-        if (more) dma_chroma(n_img, n_syi, n_sxi, lane, role_of(trip + 1));
+        if (!dyn) take(cur + (int)gridDim.x);
         const uint32_t ready_seen = lds_peek(ready);
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(13)
@@ -426,6 +450,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         // ---- the stack's tile is complete: everyone's samples of this trip are in it (the wave arrived a luma transform
         //      ago; it was read then so that the check costs no round trip) ----
         lds_wait_ge_seen(ready, (uint32_t)(QS * (trip + 1)), ready_seen);
+        if (dyn) take(drawn());   // the prefetch lands during the pixel rows
         JA_PHASE(9)
         {
             // the sample row above the wave's first / below its last where it is not in the plane: image top / bottom (a
@@ -574,6 +599,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         __builtin_amdgcn_sched_barrier(0);
         store_row(7);
         JA_PHASE(10)
+        if (!more) break;
+    }
+    // every workgroup has drawn its last ticket (the one past the end) before it gets here: the last one to leave resets
+    // both counters for the next launch on this stream
+    if (dyn && threadIdx.x == 0) {
+        const uint32_t f = __hip_atomic_fetch_add(a.tickets + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f == gridDim.x - 1) {
+            __hip_atomic_store(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     JA_PHASE_FLUSH((int)blockIdx.x * NW + qp, lane0)
 }
@@ -654,7 +689,7 @@ QuadCut quad_cut(int ux, int uy, long n_images, long resident)
 }
 
 hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const PlaneSet &coef, QuantaRef q,
-                              bool rgb, uint8_t *d_pixels, size_t pixel_stride)
+                              bool rgb, uint32_t *d_walk_counters, uint8_t *d_pixels, size_t pixel_stride)
 {
     QuadArgs a{};
     for (int p = 0; p < 3; ++p) {
@@ -677,6 +712,11 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
         const long nstacks = (long)a.stacks_per_image * n_images;
         if (nstacks > 0x3fffffffL) return hipErrorInvalidValue;
         a.nstacks = (int)nstacks;
+        // tickets for walks of at least 16 trips (kernel header: shorter ones are better planned than drawn)
+#ifndef JA_X_TICKET_TRIPS
+#define JA_X_TICKET_TRIPS 16
+#endif
+        a.tickets = nstacks >= (long)(JA_X_TICKET_TRIPS) * quad_resident_workgroups<1, 32, true>() ? d_walk_counters : nullptr;
         hipError_t e;
         if (bx == 16) e = fast ? (rgb ? launch_quad<1, 16, true>(stream, a) : launch_quad<0, 16, true>(stream, a))
                                : (rgb ? launch_quad<1, 16, false>(stream, a) : launch_quad<0, 16, false>(stream, a));

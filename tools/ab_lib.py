@@ -5,6 +5,8 @@ rounds, median and minimum per build and case.  usage (GPU box): tools/ab_lib.py
 import sys, os, subprocess, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("200", "8192", "8192", "1"), ("30", "1920", "1080", "512"), ("300", "4096", "4096", "1"), ("100", "1920", "1080", "64")]
+if os.environ.get("AB_CASES"):   # e.g. AB_CASES="100:1920:1080:128,50:2048:2048:32"  (reps:W:H:N)
+    CASES = [tuple(c.split(":")) for c in os.environ["AB_CASES"].split(",")]
 name = sys.argv[1]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 libs = {n: os.path.join(ROOT, "tools", "exp", f"libjpeg_amd_{n}.so") for n in name.split(",")}

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         // ---- the stack's tile is complete: everyone's samples of this trip are in it (the wave arrived a luma transform
         //      ago; it was read then so that the check costs no round trip) ----
         lds_wait_ge_seen(ready, (uint32_t)(QS * (trip + 1)), ready_seen);
-        if (dyn) take(drawn());   // the prefetch lands during the pixel rows
+        if (dyn) take(drawn());   // the prefetch lands during the pixel rows (that costs nothing: profiles/r03_ab_ticket_walk.txt)
         JA_PHASE(9)
         {
             // the sample row above the wave's first / below its last where it is not in the plane: image top / bottom (a

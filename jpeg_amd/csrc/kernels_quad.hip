@@ -108,16 +108,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
     // two monotonic counters.  [0] "ready": a wave has written its samples of this trip into the tile;
     // [1] "done": a wave has read the last sample of this trip.
     __shared__ uint32_t next_slot[2];                     // dynamic walk: the stack of the next trip (wave 0 publishes it, double-buffered)
-    __shared__ uint32_t qsync[2];
+    __shared__ uint32_t qsync[3];
 
     const int lane0 = threadIdx.x & 63;
     const int qp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the wave's strip of the stack; strip math stays scalar
     uint32_t *coef_w = coefbuf[qp], *stage_w = stage[qp];
     const uint32_t coef_lds = lds_address(coef_w);
     uint32_t *sc = qt + CR * qp * PITCH;                  // this wave's window: row 0 = the sample row above its own rows
-    uint32_t *ready = &qsync[0], *done = &qsync[1];
+    uint32_t *ready = &qsync[0], *done = &qsync[1], *pub = &qsync[2];   // pub: dynamic walk, "the next stack is published"
 
-    if (threadIdx.x < 2) qsync[threadIdx.x] = 0;
+    if (threadIdx.x < 3) qsync[threadIdx.x] = 0;
     __syncthreads();   // the only workgroup barrier of the walk
 
     FastDiv fd_spi, fd_tx;
@@ -389,9 +389,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 }
             }
         }
-        // this wave's samples are in the tile: arrive, do not wait yet.  (Dynamic walk: wave 0 publishes the next trip's stack
-        // BEFORE it arrives -- the LDS performs a wave's operations in order; the atomic was issued a chroma pass ago.)
-        if (dyn && qp == 0 && lane0 == 0) *(volatile uint32_t *)&next_slot[trip & 1] = gridDim.x + ticket;
+        // this wave's samples are in the tile: arrive, do not wait yet
         lds_arrive(ready);
         JA_PHASE(4)
         if (cur < second_last_round) __builtin_amdgcn_s_setprio(2);        // by rounds left after this stack
@@ -407,9 +405,15 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 cur = next;
             }
         };
-        auto drawn = [&]() -> int { return __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&next_slot[trip & 1]); };
-        if (phantom) {   // nothing to decode: the next pass's blocks, both counters, next trip
-            if (dyn) { lds_wait_ge(ready, (uint32_t)(QS * (trip + 1))); take(drawn()); }
+        // dynamic walk: wave 0 publishes the drawn stack behind its wait for the luma blocks (the atomic was issued in front of
+        // their DMA, and VM operations retire in order), the others wait for the publication -- which is a luma transform old
+        // by the time they look
+        auto drawn = [&]() -> int {
+            lds_wait_ge(pub, (uint32_t)(trip + 1));
+            return __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&next_slot[trip & 1]);
+        };
+        if (phantom) {   // nothing to decode: the next pass's blocks, both counters, next trip  (wave 0 is never phantom)
+            if (dyn) take(drawn());
             else take(cur + (int)gridDim.x);
             lds_arrive(done);
             stores_behind_dma = 0;
@@ -419,6 +423,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         JA_PHASE(11)
+        if (dyn && qp == 0) {
+            if (lane0 == 0) *(volatile uint32_t *)&next_slot[trip & 1] = gridDim.x + ticket;
+            lds_arrive(pub);
+        }
         read_block();
         // ---- the coefficient buffer is consumed: prefetch the next stack's chroma pass into it.  From here to the end of
         //      the strip only stores are issued, so nothing waits on the DMA.  (One DMA instruction in front of each column of

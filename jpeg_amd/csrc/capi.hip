@@ -25,7 +25,7 @@ struct jpeg_amd_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     uint16_t *d_qstage = nullptr;  // ring of staged host tables
-    uint32_t *d_walk = nullptr;    // two dwords, zero between launches: the ticket counters of the 4:2:0 walk (kernels_quad.hip)
+    uint32_t *d_walk = nullptr;    // the ticket counter of the 4:2:0 walk of long calls (kernels_quad.hip)
     int qslot = 0;
     int last_hip = 0;
     // staging of jpeg_amd_decompress_batch, kept between calls: two pinned host slots (the host

@@ -61,9 +61,9 @@ hipError_t launch_unpack(hipStream_t stream, const uint16_t *d_rect, size_t npix
 // Fused Spectral -> YCbCr / RGB bytes (kernels_fused.hip): 8-bit y8 images, and ycc8 images
 // with full-factor luma and 1x / 2x subsampled chroma, centred upsampling.
 bool       fused_decode_supported(const jpeg_amd_layout &layout, bool cosited);
-// No intermediate in HBM for any layout.  `d_walk_counters`: two zero-initialised dwords that the caller keeps for the
-// stream (jpeg_amd_ctx owns a pair): the 4:2:0 walk of a long call hands its stacks out through them and leaves them
-// zero again; nullptr: always the static walk.
+// No intermediate in HBM for any layout.  `d_walk_counters`: a device dword that the caller keeps for the stream
+// (jpeg_amd_ctx owns one): the 4:2:0 walk of a long call hands its stacks out through it (zeroed in front of the launch,
+// on the stream); nullptr: always the static walk.
 hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_layout &layout,
                                const PlaneSet &coef, QuantaRef q, bool rgb, uint32_t *d_walk_counters,
                                uint8_t *d_pixels, size_t pixel_stride);

@@ -61,8 +61,8 @@ struct QuadArgs {
     size_t out_stride;
     int tiles_x;                   // strip columns this launch walks ...
     int sx0;                       // ... starting at this one (units of BX blocks)
-    uint32_t *tickets;             // dynamic walk (long calls): [0] stacks handed out beyond the first round, [1] workgroups
-                                   // that have finished; nullptr: workgroup b walks stacks b, b + grid, b + 2 grid ...
+    uint32_t *tickets;             // dynamic walk (long calls): the number of stacks handed out beyond the first round (zeroed by
+                                   // the host in front of the launch); nullptr: workgroup b walks stacks b, b + grid, b + 2 grid ...
     int stacks_per_image;          // tiles_x * stack rows
     int nstacks;                   // of the whole call
 };
@@ -609,15 +609,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         JA_PHASE(10)
         if (!more) break;
     }
-    // every workgroup has drawn its last ticket (the one past the end) before it gets here: the last one to leave resets
-    // both counters for the next launch on this stream
-    if (dyn && threadIdx.x == 0) {
-        const uint32_t f = __hip_atomic_fetch_add(a.tickets + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (f == gridDim.x - 1) {
-            __hip_atomic_store(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     JA_PHASE_FLUSH((int)blockIdx.x * NW + qp, lane0)
 }
 
@@ -725,6 +716,10 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
 #define JA_X_TICKET_TRIPS 16
 #endif
         a.tickets = nstacks >= (long)(JA_X_TICKET_TRIPS) * quad_resident_workgroups<1, 32, true>() ? d_walk_counters : nullptr;
+        if (a.tickets) {   // (a 2 us node in front of a call of a millisecond or more)
+            const hipError_t m = hipMemsetAsync(a.tickets, 0, sizeof(uint32_t), stream);
+            if (m != hipSuccess) return m;
+        }
         hipError_t e;
         if (bx == 16) e = fast ? (rgb ? launch_quad<1, 16, true>(stream, a) : launch_quad<0, 16, true>(stream, a))
                                : (rgb ? launch_quad<1, 16, false>(stream, a) : launch_quad<0, 16, false>(stream, a));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the mixed column cut of k_quad420 (quad_cut, kernels_quad.hip): batches long enough to be cut into 32 x 2 strips
+"""Soak of the mixed column cut and of the ticket walk of k_quad420 (quad_cut, dynamic walk: kernels_quad.hip): batches long enough to be cut into 32 x 2 strips
 for the whole columns + one column of 16 x 4 strips, random sizes whose remainder column is 1 .. 16 blocks wide -- odd
 widths (byte-wise store tail), partial remainder columns, short last stacks on either side of the seam -- against the oracle
 on a sample of the batch.
@@ -25,7 +25,8 @@ for it in range(int(sys.argv[2])):
     ux, uy = units[0]
     wide, narrow = stacks(-(-ux // 32), uy, 2), stacks(-(-ux // 16), uy, 4)
     mixed = stacks(ux // 32, uy, 2) + stacks(1, uy, 4)
-    n = -(-16 * 768 // min(wide, narrow)) + int(rng.integers(0, 3))           # just long enough for the cut to be considered
+    n = -(-16 * 768 // min(wide, narrow)) + int(rng.integers(0, 3))           # just long enough for the cut to be considered ...
+    if rng.integers(2): n = n * 2                                             # ... or long enough for the ticket walk in both launches
     if w * h * n > 400_000_000: continue
     cut += int(mixed < min(wide, narrow) and 0 < ux % 32 <= 16)
     pool = [np.clip(rng.laplace(0, 60, (4, b, a, 64)), -1024, 1023).astype(np.int16) for a, b in units]

@@ -105,3 +105,38 @@ def test_420_large_batches_take_the_mixed_column_cut(env, size, n):
     for i in sorted({0, 1, n // 3, n // 2, n - 2, n - 1}):
         _, rect = O.decode([h[i] for h in host], [quanta[0], quanta[1], quanta[1]], [(2, 2), (1, 1), (1, 1)], size, threads=8)
         assert (out[i].cpu().numpy() == O.unpack_rgb8(rect, 3, threads=8).reshape(-1)).all(), i
+
+
+@pytest.mark.parametrize("size,n", [((1920, 1080), 128), ((256, 64), 13000), ((272, 200), 2100)])
+def test_420_long_calls_take_the_ticket_walk(env, size, n):
+    """Calls of 16 or more trips per workgroup (>= 12 288 stacks in a launch) hand their stacks out through a ticket counter
+    instead of the static stride (k_quad420, dynamic walk): every image of the batch against the oracle's result for its
+    source (a pool of 8 distinct images), twice in a row on the same context (the counter is zeroed per launch)."""
+    J, O, ctx = env
+    import torch
+    from jpeg_amd import _lib
+    import ctypes as C
+    rng = np.random.default_rng(23)
+    quanta = [rng.integers(1, 30, 64).astype(np.uint16) for _ in range(2)]
+    layout = J.Layout("ycc8", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    units = layout.units(size)
+    W, H = size
+    dev = ctx.torch_device
+    pool = [np.clip(rng.laplace(0, 40, (8, uy, ux, 64)), -1000, 1000).astype(np.int16) for ux, uy in units]
+    idx = rng.integers(0, 8, n)
+    d_planes = [torch.from_numpy(p[idx]).to(dev) for p in pool]
+    d_q = torch.from_numpy(np.stack(quanta).view(np.int16)).to(dev)
+    L = layout.c_layout(size, units, [0, 1, 1])
+    strides = _lib.size_array([64 * a * b for a, b in units])
+    want = []
+    for k in range(8):
+        _, rect = O.decode([p[k] for p in pool], [quanta[0], quanta[1], quanta[1]], [(2, 2), (1, 1), (1, 1)], size, threads=8)
+        want.append(torch.from_numpy(O.unpack_rgb8(rect, 3, threads=8).reshape(-1)).to(dev))
+    want = torch.stack(want)[torch.from_numpy(idx).to(dev)]
+    for rep in range(2):
+        out = torch.zeros((n, W * H * 3), dtype=torch.uint8, device=dev)
+        st = _lib.lib().jpeg_amd_decode_batch(ctx.handle, C.byref(L), n, _lib.ptr_array([p.data_ptr() for p in d_planes]), strides,
+                                              d_q.data_ptr(), 0, 2, 0, _lib.COLOR_RGB8, out.data_ptr(), W * H * 3)
+        assert st == 0
+        bad = (out != want).any(dim=1)
+        assert not bool(bad.any()), (rep, int(bad.sum()), int(torch.nonzero(bad)[0]))

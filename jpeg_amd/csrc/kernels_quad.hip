@@ -122,15 +122,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
 
     FastDiv fd_spi, fd_tx;
     fd_spi.set((uint32_t)a.stacks_per_image); fd_tx.set((uint32_t)a.tiles_x);
-    // trip t of this workgroup: stack blockIdx.x + t gridDim.x -> image, strip row of this wave, strip column
-    auto stack_of = [&](int t) -> int { return (int)blockIdx.x + t * (int)gridDim.x; };
+    // stack -> image, strip row of this wave, strip column
     auto locate = [&](int q, int &img, int &syi, int &sxi) {
         uint32_t rem, col;
         img = (int)fd_spi.div((uint32_t)q, rem);
         syi = QS * (int)fd_tx.div(rem, col) + qp;
         sxi = (int)col + a.sx0;
     };
-    const int trips = (a.nstacks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // stacks this workgroup walks
     const int strips_y = (a.uy + BY - 1) / BY;
     auto role_of = [&](int t) -> int { return (qp + 2 * (t & 1)) & 3; };
 
@@ -233,7 +231,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
 #ifdef JA_X_STAGGER   // experiment: the three workgroups of a CU start a third of a strip apart
     for (int d = (int)(blockIdx.x / 256u) * (JA_X_STAGGER); d > 0; d -= 64 * 100) __builtin_amdgcn_s_sleep(100);
 #endif
-    if (trips <= 0) return;
+    if ((int)blockIdx.x >= a.nstacks) return;   // (the grid is never larger than the call)
     // The walk.  Static (a.tickets == nullptr): workgroup b takes stacks b, b + grid, ...  Dynamic, for calls that are many
     // trips long: the first stack is b, every further one a ticket from a global counter -- wave 0 draws it at the top of a
     // trip and publishes it in LDS before its arrival at "ready", the others pick it up behind their wait for "ready".  A
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
     int cur = (int)blockIdx.x;
     const int last_round = a.nstacks - (int)gridDim.x, second_last_round = a.nstacks - 2 * (int)gridDim.x;
     int c_img, c_syi, c_sxi;   // the current trip's stack (located once, a trip ahead)
-    locate(stack_of(0), c_img, c_syi, c_sxi);
+    locate(cur, c_img, c_syi, c_sxi);
     dma_chroma(c_img, c_syi, c_sxi, lane0, role_of(0));
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform

@@ -23,6 +23,28 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-command-line-argument"]
 
 
+# kernels that must not touch scratch memory: source -> mangled-name fragment
+NO_SCRATCH = {"kernels_quad.hip": "k_quad420", "kernels_fused.hip": "k_luma_fused"}
+
+
+def check_no_scratch(src: str, remarks: str, fragment: str) -> None:
+    """Parse hipcc's kernel-resource-usage remarks: every kernel whose name contains `fragment` must report
+    ScratchSize 0 and no spilled registers."""
+    cur, seen, bad = None, 0, []
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            cur = line.split("Function Name:")[1].split("[-R")[0].strip()
+            seen += fragment in cur
+        elif cur and fragment in cur:
+            for key in ("ScratchSize [bytes/lane]:", "VGPRs Spill:"):
+                if key in line and int(line.split(key)[1].split("[-R")[0].strip()) != 0:
+                    bad.append(f"{cur}: {key} {line.split(key)[1].split('[-R')[0].strip()}")
+    if seen == 0:
+        raise RuntimeError(f"{src}: no resource remarks for {fragment} (the spill gate cannot see the kernels)")
+    if bad:
+        raise RuntimeError(f"{src}: kernels that count their own VM operations must not spill:\n  " + "\n  ".join(bad))
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -39,7 +61,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def sync_swift_header() -> None:
+    """swift/Sources/CJPEGAMD/jpeg_amd.h is a generated copy of include/jpeg_amd.h (the module map needs the header inside
+    the C target's directory); tests/test_abi_cpu.py checks that the two are identical."""
+    src = os.path.join(INCLUDE, "jpeg_amd.h")
+    dst = os.path.join(os.path.dirname(HERE), "swift", "Sources", "CJPEGAMD", "jpeg_amd.h")
+    if os.path.isdir(os.path.dirname(dst)):
+        data = open(src, "rb").read()
+        if not os.path.exists(dst) or open(dst, "rb").read() != data:
+            open(dst, "wb").write(data)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    sync_swift_header()
     if not (force or _stale()):
         return LIB
     cc = hipcc()
@@ -49,7 +83,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
         cmd = [cc, *FLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        if src in NO_SCRATCH:
+            # these kernels count their own VM operations (`s_waitcnt vmcnt(16)` behind the coefficient DMA): a compiler-
+            # generated scratch store or reload in that window would break the count, so a spill is a build error
+            proc = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+            remarks = [l for l in proc.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l]
+            if remarks:
+                sys.stderr.write("\n".join(remarks) + "\n")
+            if proc.returncode != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+            check_no_scratch(src, proc.stderr, NO_SCRATCH[src])
+        else:
+            subprocess.check_call(cmd)
         objs.append(obj)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
     if verbose:

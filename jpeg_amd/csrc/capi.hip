@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <chrono>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -306,10 +307,17 @@ int jpeg_amd_timer_end(jpeg_amd_ctx *ctx, float *elapsed_ms)
     JA_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     // poll instead of sleeping on the event: a blocked host thread takes tens of microseconds to wake up, which a caller
     // that brackets a short timed region with its own clock would charge to the region
-    hipError_t q;
-    while ((q = hipEventQuery(ctx->ev_end)) == hipErrorNotReady) {}
+    // -- but only for a bounded time (200 us): a long region (the PCIe-bound file paths, a rank per core) must not burn a host
+    // core, so after that the thread sleeps on the event like everybody else
+    hipError_t q = hipErrorNotReady;
+    const auto give_up = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+    while ((q = hipEventQuery(ctx->ev_end)) == hipErrorNotReady && std::chrono::steady_clock::now() < give_up) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (q == hipErrorNotReady) q = hipEventSynchronize(ctx->ev_end);
     JA_HIP(ctx, q);
-    JA_HIP(ctx, hipEventSynchronize(ctx->ev_end));
     JA_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
     return JPEG_AMD_OK;
 }
@@ -889,7 +897,11 @@ try {
         // asynchronously: they are complete once that chunk's kernels are (file_decoded[slot] was recorded behind
         // them).  The helper thread that copies chunk k - 2's pixels out of the same slot may still be running; it
         // only reads the pixel region, which the decode below does not touch.
-        if (k >= 2) JA_HIP(ctx, hipEventSynchronize(ctx->file_decoded[slot]));
+        // (like every failure inside this loop it leaves through the common tail below, which waits for both streams)
+        if (k >= 2) {
+            const hipError_t w = hipEventSynchronize(ctx->file_decoded[slot]);
+            if (w != hipSuccess) { ctx->last_hip = (int)w; result = JPEG_AMD_EHIP; break; }
+        }
         std::vector<int> status((size_t)m, JPEG_AMD_OK);
         parallel(m, [&](int i) {
             int16_t *planes[JPEG_AMD_MAX_PLANES] = {};

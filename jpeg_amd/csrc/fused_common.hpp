@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace jpeg_amd {
 
 constexpr int kThreads = 256;
@@ -85,6 +87,28 @@ __device__ __forceinline__ void lds_dma16_run(uint64_t sbase, uint32_t v0, uint3
 __device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32_t lds)
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds) : "memory");
+}
+
+// Resident workgroups of a persistent kernel on the CURRENT device: workgroups per CU (what the occupancy query says for this
+// instantiation) x CUs.  One cache per instantiation (TAG = the kernel's type) and per device, filled once under
+// std::call_once: contexts of several devices, and first calls from several host threads, see their own device's value.
+constexpr int kMaxDevices = 64;
+template <typename Kernel>
+inline int resident_workgroups_of(Kernel kernel, int fallback_per_cu)
+{
+    struct PerDevice { std::once_flag once; int value = 0; };
+    static PerDevice cache[kMaxDevices];   // one array per Kernel type, i.e. per instantiation
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    auto query = [&]() {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = fallback_per_cu;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        return per_cu * cus;
+    };
+    if (dev >= kMaxDevices) return query();
+    std::call_once(cache[dev].once, [&]() { cache[dev].value = query(); });
+    return cache[dev].value;
 }
 
 // LDS byte address of a __shared__ object (low 32 bits of its flat address), wave-uniform

@@ -663,16 +663,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
 template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX>
 int resident_workgroups()
 {
-    static int cached = 0;  // one per instantiation
-    if (cached == 0) {
-        auto kernel = k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX>;
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        cached = per_cu * cus;
-    }
-    return cached;
+    return resident_workgroups_of(k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX>, 2);
 }
 
 template <int MODE, bool FAST, int BX>

@@ -67,6 +67,9 @@ struct QuadArgs {
     int nstacks;                   // of the whole call
 };
 
+#ifndef JA_QUAD_WAVES
+#define JA_QUAD_WAVES 3   // waves per SIMD the register allocation aims at
+#endif
 template <int BX> struct QuadShape {
     static constexpr int BY = 64 / BX;
     static constexpr int QS = kThreads / 64;              // strips (= waves) per stack: one stack per workgroup
@@ -75,7 +78,7 @@ template <int BX> struct QuadShape {
 // MODE: 0 = YCbCr bytes, 1 = RGB bytes.  FAST: W % 16 == 0 and 16-byte aligned rows, so every 16-byte chunk of a row
 // segment is entirely inside the image or entirely outside (no byte-wise tail code).
 template <int MODE, int BX, bool FAST>
-__global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
+__global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 {
     constexpr int BY = QuadShape<BX>::BY, QS = QuadShape<BX>::QS;
     constexpr int NW = kThreads / 64;
@@ -101,7 +104,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
     constexpr int NHROW = 4 * CBW, NSIDE = 4 * (QS * CBR + 2);   // blocks of role 2 / role 3: 64 / 24 (32 x 2 strips), 32 / 40
     constexpr int NDMA_C = 8;                             // LDS-DMA instructions of a chroma pass at most (8 blocks each)
 
+#ifdef JA_X_LDSHACK   // experiment (wrong pixels): pairs of waves share a coefficient buffer -- what are four waves per SIMD worth?
+    __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW / 2][64 * 32];
+#else
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];   // 8 KiB per wave
+#endif
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     __shared__ uint32_t qt[2 * PLANE];                    // the stack's tile; row 0: halo above, rows 1 + CR p ...: strip p, last row: halo below
     __shared__ float sqw[NW][3][64];                      // modulated tables: Y, Cb, Cr
@@ -112,7 +119,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
 
     const int lane0 = threadIdx.x & 63;
     const int qp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the wave's strip of the stack; strip math stays scalar
+#ifdef JA_X_LDSHACK
+    uint32_t *coef_w = coefbuf[qp & 1], *stage_w = stage[qp];
+#else
     uint32_t *coef_w = coefbuf[qp], *stage_w = stage[qp];
+#endif
     const uint32_t coef_lds = lds_address(coef_w);
     uint32_t *sc = qt + CR * qp * PITCH;                  // this wave's window: row 0 = the sample row above its own rows
     uint32_t *ready = &qsync[0], *done = &qsync[1], *pub = &qsync[2];   // pub: dynamic walk, "the next stack is published"
@@ -438,18 +449,22 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
         JA_PHASE(13)
 
         // ---- luma: dequantise + IDCT, clamp + truncate (decode.swift:4121-4122), kept as integer-valued floats ----
-        float yv[64];
-#ifdef JA_X_NOIDCT  // experiment: how long is a strip without the IDCT arithmetic?
+        // the samples wait for their pixel row as packed bytes (16 registers instead of 64): clamp + truncate is the
+        // saturating convert under round-toward-zero, and a row unpacks its eight bytes with v_cvt_f32_ubyte0..3
+        uint32_t ypk[16];
+        {
+            float yv[64];
+#ifdef JA_X_NOIDCT  // experiment (wrong pixels): how long is a strip without the IDCT arithmetic?
 #pragma unroll
-        for (int i = 0; i < 64; ++i) yv[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff);
+            for (int i = 0; i < 64; ++i) yv[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff);
 #else
-        idct_block(w, sqw[qp][0], 128.5f, yv);
-#pragma unroll
-        for (int i = 0; i < 64; ++i) yv[i] = floorf(__builtin_amdgcn_fmed3f(yv[i], 0.0f, 255.0f));
+            idct_block(w, sqw[qp][0], 128.5f, yv);
 #endif
+            trunc_pack24(yv, ypk); trunc_pack24(yv + 24, ypk + 6); trunc_pack16(yv + 48, ypk + 12);
+        }
         // pin the IDCT here (LLVM otherwise sinks it into the pixel rows)
 #pragma unroll
-        for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(yv[i]));
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(ypk[i]));
         __builtin_amdgcn_sched_barrier(0);
         JA_PHASE(6)
 
@@ -570,7 +585,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
                 float c[24];
 #pragma unroll
                 for (int x = 0; x < 8; ++x) {
-                    const float yy = yv[8 * y + x];
+                    const float yy = x == 0 ? ubyte<0>(ypk[2 * y]) : x == 1 ? ubyte<1>(ypk[2 * y]) : x == 2 ? ubyte<2>(ypk[2 * y]) : x == 3 ? ubyte<3>(ypk[2 * y])
+                                   : x == 4 ? ubyte<0>(ypk[2 * y + 1]) : x == 5 ? ubyte<1>(ypk[2 * y + 1]) : x == 6 ? ubyte<2>(ypk[2 * y + 1]) : ubyte<3>(ypk[2 * y + 1]);
                     if constexpr (MODE == 1) {
                         const float pb = cv[0][x], pr = cv[1][x];
                         // jpeg.swift:441-453: x = (y + m_cb cb) + m_cr cr, clamped and TRUNCATED -- the pack below.  One FMA
@@ -614,15 +630,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_quad420(QuadArgs a)
 template <int MODE, int BX, bool FAST>
 int quad_resident_workgroups()
 {
-    static int cached = 0;  // one per instantiation
-    if (cached == 0) {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_quad420<MODE, BX, FAST>, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        cached = per_cu * cus;
-    }
-    return cached;
+    return resident_workgroups_of(k_quad420<MODE, BX, FAST>, 2);
 }
 
 template <int MODE, int BX, bool FAST>
@@ -701,7 +709,14 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
     a.out = d_pixels; a.out_stride = pixel_stride;
     if (n_images == 0 || a.ux == 0 || a.uy == 0) return hipSuccess;
     const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
-    const QuadCut cut = quad_cut(a.ux, a.uy, n_images, quad_resident_workgroups<1, 32, true>());
+    // every decision is sized from the instantiation it concerns (colour target x strip shape x store path)
+    auto resident = [&](int bx) -> int {
+        if (bx == 16) return fast ? (rgb ? quad_resident_workgroups<1, 16, true>() : quad_resident_workgroups<0, 16, true>())
+                                  : (rgb ? quad_resident_workgroups<1, 16, false>() : quad_resident_workgroups<0, 16, false>());
+        return fast ? (rgb ? quad_resident_workgroups<1, 32, true>() : quad_resident_workgroups<0, 32, true>())
+                    : (rgb ? quad_resident_workgroups<1, 32, false>() : quad_resident_workgroups<0, 32, false>());
+    };
+    const QuadCut cut = quad_cut(a.ux, a.uy, n_images, std::max(resident(32), resident(16)));
     for (int part = 0; part < cut.parts; ++part) {
         const int bx = cut.bx[part];
         a.tiles_x = cut.cols[part]; a.sx0 = cut.sx0[part];
@@ -713,7 +728,7 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
 #ifndef JA_X_TICKET_TRIPS
 #define JA_X_TICKET_TRIPS 16
 #endif
-        a.tickets = nstacks >= (long)(JA_X_TICKET_TRIPS) * quad_resident_workgroups<1, 32, true>() ? d_walk_counters : nullptr;
+        a.tickets = nstacks >= (long)(JA_X_TICKET_TRIPS) * resident(bx) ? d_walk_counters : nullptr;
         if (a.tickets) {   // (a 2 us node in front of a call of a millisecond or more)
             const hipError_t m = hipMemsetAsync(a.tickets, 0, sizeof(uint32_t), stream);
             if (m != hipSuccess) return m;

@@ -38,9 +38,12 @@ UNPRIVATE = {"sources/jpeg/decode.swift": [1433, 1575]}   # lines that consist o
 
 
 def main():
-    if len(sys.argv) < 2:
-        raise SystemExit(__doc__)
+    if len(sys.argv) < 2 or sys.argv[1] in ("-h", "--help") or sys.argv[1].startswith("-"):
+        print(__doc__)
+        raise SystemExit(0 if len(sys.argv) > 1 and sys.argv[1] in ("-h", "--help") else 2)
     checkout = sys.argv[1]
+    if not os.path.isdir(os.path.join(checkout, "sources", "jpeg")):
+        raise SystemExit(f"{checkout}: not a checkout of tayloraswift/jpeg (no sources/jpeg)")
     here = sys.argv[2] if len(sys.argv) > 2 else os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     for rel, want in EXPECT.items():
         data = open(os.path.join(checkout, rel), "rb").read()

@@ -33,6 +33,14 @@ def test_binding_covers_the_header():
     assert sorted(_lib.SIGNATURES) == _declared()
 
 
+def test_swift_module_header_is_the_generated_copy():
+    """swift/Sources/CJPEGAMD/jpeg_amd.h (what the module map exposes to Swift) is a COPY of include/jpeg_amd.h made by
+    jpeg_amd.build.sync_swift_header(); the two must never drift."""
+    a = open(os.path.join(ROOT, "include", "jpeg_amd.h"), "rb").read()
+    b = open(os.path.join(ROOT, "swift", "Sources", "CJPEGAMD", "jpeg_amd.h"), "rb").read()
+    assert a == b, "run `python -m jpeg_amd.build` (it regenerates the Swift module's header from include/jpeg_amd.h)"
+
+
 def test_version_and_strerror():
     L = _lib.lib()
     assert L.jpeg_amd_version() == 100

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 SIZES = [
     (2048, 1024),    # whole stacks, whole columns (the shape of config 3)
     (2048, 1540),    # 96.25 strips of 32 x 2: a short last stack and a partial last strip
-    (1920, 1080),    # config 5: 16 x 4 strips, 15 x 34, whole stacks of two
+    (1920, 1080),    # config 5: one image takes 16 x 4 strips (15 x 34, 135 stacks); long batches the mixed cut (7 columns of 32 x 2 + 1 of 16 x 4)
     (3840, 2160),    # 135 strip rows of 32 x 2 (33.75 stacks) -> 16 x 4 strips, 30 x 68
     (2064, 192),     # partial last column of 32 x 2 strips
     (4112, 520),     # partial last column and partial last strip

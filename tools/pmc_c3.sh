@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/pmc_c3.sh <tag> [run_c3 args]   -- SQ counter passes of tools/run_c3.py under the current JPEG_AMD_BAND
+# usage (GPU box): bash tools/pmc_c3.sh <tag> [run_c3 args]   -- SQ counter passes of tools/run_c3.py of the library JPEG_AMD_LIBRARY selects (default: the product build)
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp

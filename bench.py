@@ -9,15 +9,18 @@ A step = one pass of jpeg_amd_decode_batch over one batch of synthetic coefficie
 already resident in HBM (host Huffman decoding and PCIe transfers are out of scope and
 excluded; see DESIGN.md "Measurement").
 
-Workload c3 (BASELINE.json configs[2], the configuration the metric is quoted on; the default at
-N = 1): one 8192x8192 ycc8 4:2:0 image per GPU per step; the step rotates through a ring of distinct
-images so that the 256 MiB Infinity Cache cannot serve the input.  With --gpus N > 1 it scales weakly
-(every rank its own image).
-Workload c5 (configs[4]; the default at N > 1): ONE job of 4096 independent 1920x1080 images per
-step, sharded over the ranks with jpeg_amd.dist.shard (contiguous chunks: 512 per GPU at N = 8, all
-4096 = 51 GB of coefficients + pixels on the one GPU at N = 1) -- strong scaling.  At N = 1 the
-default line also carries the same job in `extra.c5_4096x1080p`, so that a 1/2/4/8 curve has its
-N = 1 point on the same workload.
+Workload c3 (BASELINE.json configs[2], the configuration the metric is quoted on; `value` at EVERY N): one
+8192x8192 ycc8 4:2:0 image per GPU per step; the step rotates through a ring of distinct images so that the
+256 MiB Infinity Cache cannot serve the input.  With --gpus N > 1 every rank decodes its own image: weak scaling,
+the same per-GPU work at every N, so a 1/2/4/8 curve built from `value` compares like with like.
+The C5 job (configs[4]): ONE job of 4096 independent 1920x1080 images, sharded over the ranks with
+jpeg_amd.dist.shard (contiguous chunks: 512 per GPU at N = 8, all 4096 = 51 GB of coefficients + pixels on the one
+GPU at N = 1) -- strong scaling -- is measured collectively (barrier, max over ranks) at EVERY N right after the
+headline and reported as `extra.c5_4096x1080p`; a strong-scaling curve is built from ITS `Mpixels_per_s`.
+`--workload c5` makes that job the headline instead (`value`, "scaling": "strong").
+Every rank proves what it timed: one image of its shard is decoded again on its own, compared with the batch result on
+the device and with the CPU oracle on the host (`per_rank[i].parity_vs_oracle`, `single_equals_batch`), for the
+headline and for the C5 job.
 There is no data-path collective in either workload: every rank decodes its own independent images;
 the only collective is an RCCL broadcast of the quantisation tables from rank 0 before the timed
 region.
@@ -49,7 +52,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="auto", choices=["auto", "c3", "c5"],
-                    help="auto: c3 at N = 1 (the headline), c5 at N > 1 (4096 x 1080p sharded over the ranks)")
+                    help="auto = c3 at every N (weak scaling, the headline); c5: the sharded 4096 x 1080p job as the headline")
+    ap.add_argument("--no-c5-job", action="store_true", help="skip the collective C5 job leg (extra.c5_<n>x1080p)")
+    ap.add_argument("--c5-steps", type=int, default=5)
+    ap.add_argument("--no-parity", action="store_true", help="skip the per-rank comparison with the CPU oracle")
     ap.add_argument("--c5-images", type=int, default=4096, help="images of the c5 job (all ranks together)")
     ap.add_argument("--ring", type=int, default=0, help="distinct image sets to rotate through")
     ap.add_argument("--no-extras", action="store_true", help="skip the C2/C4/C5 side measurements")
@@ -112,6 +118,25 @@ class DecodeWorkload:
         import torch
         return torch.cuda.get_device_name(self.ctx.torch_device)
 
+    def verify(self, quanta_np, image=0, threads=8):
+        """What this rank just timed, proven on one image of its shard (image `image` of ring slot 0, which every step count
+        >= 1 has decoded): decoded again ON ITS OWN (a batch of one) and compared with the batch result on the device, then
+        compared with the CPU oracle on the host.  Every pixel is a function of its own image's coefficients only
+        (decode.swift:4114-4117), so one image per rank is a witness of the whole shard's code path."""
+        import torch
+        res = {"image_checked": int(image), "single_equals_batch": None}
+        if self.n_images > 1:
+            alone = torch.empty(self.pixel_stride, dtype=torch.uint8, device=self.out.device)
+            ptrs = self._lib.ptr_array([p[image].data_ptr() for p in self.planes])
+            st = self._fn(self.ctx.handle, C.byref(self.L), 1, ptrs, self._strides, self.d_quanta.data_ptr(), 0, 2, 0,
+                          self._lib.COLOR_RGB8, alone.data_ptr(), self.pixel_stride)
+            if st != 0:
+                raise self._lib.JpegAmdError(st, "jpeg_amd_decode_batch", 0)
+            res["single_equals_batch"] = bool(torch.equal(alone, self.out[image]))
+        planes, pixels = self.host_case(image)
+        res["parity_vs_oracle"] = oracle_check(planes, pixels, self.size, quanta_np, threads)
+        return res
+
     def host_case(self, image=0):
         """Coefficient planes and the pixels the device produced for one image of the LAST step:
         what the cpu_baseline leg decodes again on the host and compares (not timed)."""
@@ -132,6 +157,14 @@ def time_region(wl, fn, steps, sync, barrier):
     sync()
     barrier()
     return time.perf_counter() - t0, gpu_ms
+
+
+def oracle_check(planes, pixels, size, quanta_np, threads):
+    """Checker half of the cpu_baseline leg (oracle/ is test infrastructure and is only ever the CHECKER here, never the
+    thing timed as the product): decode `planes` (ycc8 4:2:0) on the host and compare with the device's RGB8 `pixels`."""
+    from oracle import oracle as O
+    _, rect = O.decode(planes, [quanta_np[0], quanta_np[1], quanta_np[1]], [(2, 2), (1, 1), (1, 1)], tuple(size), threads=threads)
+    return bool((O.unpack_rgb8(rect, 3, threads=threads) == pixels.reshape(-1, 3)).all())
 
 
 def cpu_baseline(J, quanta_np, seconds, device_case=None, encode_case=None):
@@ -298,7 +331,8 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
     if dist is not None:
         assert (d_quanta.cpu().numpy().view(np.uint16) == q_np).all()
 
-    workload = args.workload if args.workload != "auto" else ("c3" if world == 1 else "c5")
+    workload = args.workload if args.workload != "auto" else "c3"   # ONE workload under `value` at every N
+    check_threads = max(1, min(64, (os.cpu_count() or 1) // world))
     if make_workload is None:
         def make_workload(name, width, height, n_images, ring, quanta, seed):
             return DecodeWorkload(J, ctx, width, height, n_images, ring, quanta, seed)
@@ -329,9 +363,11 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
     wall, gpu_ms = time_region(wl, wl.step, args.steps, sync, barrier)
     wall_max = jd.max_over_ranks(wall, dev, dist)
 
-    # per-rank record (device, images, times), gathered on every rank; rank 0 reports it
+    # per-rank record (device, images, times, and the proof of what was timed), gathered on every rank; rank 0 reports it
     mine = {"rank": rank, "device": wl.device_name(), "images_per_step": wl.n_images,
             "wall_ms_per_step": round(wall / args.steps * 1e3, 5), "gpu_ms_per_step": round(gpu_ms / args.steps, 5)}
+    if not args.no_parity and wl.n_images > 0:
+        mine.update(wl.verify(q_np, image=(wl.n_images - 1) // 2, threads=check_threads))
     per_rank = [mine]
     if dist is not None:
         per_rank = [None] * world
@@ -379,6 +415,12 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
             ctx2.close()
         except Exception as e:   # a side measurement must not take the bench line with it
             two_streams = {"error": repr(e)[:200]}
+
+    # ---- the sharded C5 job (BASELINE.json configs[4]) at EVERY N, measured collectively: the strong-scaling curve is built
+    #      from this record's Mpixels_per_s; `value` above stays on one workload ----
+    c5_job = None
+    if workload != "c5" and not args.no_c5_job:
+        c5_job = run_c5_job(args, make_workload, d_quanta, q_np, rank, world, dev, dist, sync, barrier, check_threads)
 
     result = None
     if rank == 0:
@@ -436,11 +478,18 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
                          "kernels": "all kernels of one fused decode step (rank 0's shard)"},
         }
 
+    if rank == 0:
+        result["scaling_curve"] = ("`value` is workload " + workload + " at every N (" + scaling + " scaling); the sharded C5 job is "
+                                   "extra.c5_%dx1080p.Mpixels_per_s at every N (strong scaling)" % args.c5_images)
+        checks = [r.get("parity_vs_oracle") for r in per_rank]
+        result["parity_vs_oracle"] = None if any(c is None for c in checks) else bool(all(checks))
+        if c5_job is not None:
+            result.setdefault("extra", {})["c5_%dx1080p" % args.c5_images] = c5_job
     # ---- not timed: side measurements, CPU baseline (+ parity of what was just measured) ----
     if rank == 0 and device_kind == "cuda":
         encode_case = None
         if world == 1 and not args.no_extras:
-            result["extra"] = extras(J, ctx, d_quanta, q_np, sync, args, workload)
+            result.setdefault("extra", {}).update(extras(J, ctx, d_quanta, q_np, sync, args, workload))
             if sustained:
                 result["extra"]["c3_sustained"] = sustained
             if two_streams:
@@ -462,7 +511,10 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
             parity = cb.pop("parity")
             result["cpu_baseline"] = cb
             result["gpu_over_cpu_1core"] = round(result["value"] / cb["value"], 1)
-            result["parity_vs_oracle"] = parity.get("decode_equals_cpu")
+            if result.get("parity_vs_oracle") is None:
+                result["parity_vs_oracle"] = parity.get("decode_equals_cpu")
+            else:   # a second image (ring slot 0, image 0) checked by the baseline leg itself
+                result["parity_vs_oracle"] = bool(result["parity_vs_oracle"] and parity.get("decode_equals_cpu"))
             if "encode_equals_cpu" in parity and "extra" in result:
                 result["extra"]["c4_encode_4096"]["coefficients_equal_oracle"] = parity["encode_equals_cpu"]
     if rank == 0:
@@ -471,6 +523,55 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
     if dist is not None:
         dist.destroy_process_group()
     return result
+
+
+def run_c5_job(args, make_workload, d_quanta, q_np, rank, world, dev, dist, sync, barrier, check_threads):
+    """ONE job of args.c5_images independent 1920x1080 images, contiguous shards (jpeg_amd.dist.shard), every rank its own
+    shard, no data-path collective; barrier + synchronize on both sides of the timed steps, max over ranks.  Every rank
+    checks one image of its shard (alone == in the batch, == the CPU oracle).  Returns the record on every rank."""
+    from jpeg_amd import dist as jd
+    lo, hi = jd.shard(args.c5_images, rank, world)
+    rec = {"rank": rank, "images": hi - lo}
+    try:
+        wl = make_workload("c5", 1920, 1080, hi - lo, 1, d_quanta, 20240807 + lo) if hi > lo else None
+        step = wl.step if wl is not None else (lambda: None)
+        step()
+        sync()
+        if wl is not None:
+            wall, gpu_ms = time_region(wl, step, args.c5_steps, sync, barrier)
+            rec["gpu_ms_per_step"] = round(gpu_ms / args.c5_steps, 4)
+        else:   # more ranks than images: keep the barriers of time_region
+            barrier(); sync(); t0 = time.perf_counter(); sync(); barrier(); wall = time.perf_counter() - t0
+        rec["wall_ms_per_step"] = round(wall / args.c5_steps * 1e3, 4)
+        if wl is not None and not args.no_parity:
+            rec.update(wl.verify(q_np, image=(hi - lo - 1) // 2, threads=check_threads))
+        pixels_all, bytes_all = 1920 * 1080 * args.c5_images, None
+        if wl is not None:
+            bytes_all = wl.bytes // (hi - lo) * args.c5_images
+        del wl
+    except Exception as e:   # a side measurement must not take the bench line with it -- but every rank must still meet the collectives
+        rec["error"] = repr(e)[:200]
+        wall, pixels_all, bytes_all = float("inf"), 1920 * 1080 * args.c5_images, None
+    wall_max = jd.max_over_ranks(wall if wall != float("inf") else 1e30, dev, dist)
+    recs = [rec]
+    if dist is not None:
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+    ms = wall_max / args.c5_steps * 1e3
+    out = {"images": args.c5_images, "n_gpus": world, "steps": args.c5_steps, "scaling": "strong", "ms": round(ms, 4),
+           "Mpixels_per_s": round(pixels_all / ms / 1e3, 1), "per_rank": recs,
+           "note": "ONE job sharded contiguously over the ranks (jpeg_amd.dist.shard), barrier + max over ranks; the same job at every N"}
+    bytes_all = next((b for b in [bytes_all] if b), None)
+    if bytes_all:
+        out["GB_per_s"] = round(bytes_all / ms / 1e6, 1)
+        out["frac_hbm_per_gpu"] = round(bytes_all / ms / 1e6 / HBM_PEAK_GBS / world, 4)
+    if any("error" in r for r in recs):
+        out["error"] = [r.get("error") for r in recs]
+        out.pop("Mpixels_per_s", None)
+    checks = [r.get("parity_vs_oracle") for r in recs if r["images"] > 0]
+    out["parity_vs_oracle"] = None if (not checks or any(c is None for c in checks)) else bool(all(checks))
+    assert sum(r["images"] for r in recs) == args.c5_images
+    return out
 
 
 def main():
@@ -573,25 +674,6 @@ def extras(J, ctx, d_quanta, q_np, sync, args, workload="c3"):
         out["c4_encode_4096"]["parity_error"] = repr(e)
     del px, coefs
 
-    # C5 on this one GPU: the whole job of BASELINE.json configs[4] (4096 images of 1920x1080: 51 GB of
-    # coefficients + pixels) -- the N = 1 point of the 1/2/4/8 curve on the SAME workload `--gpus N` runs
-    if workload != "c5":
-        try:
-            wl = DecodeWorkload(J, ctx, 1920, 1080, args.c5_images, 1, d_quanta, seed=20240807)
-            wl.step()
-            sync()
-            ctx.timer_begin()
-            n = 5
-            for _ in range(n):
-                wl.step()
-            ms = ctx.timer_end() / n
-            out["c5_%dx1080p" % args.c5_images] = {
-                "images": args.c5_images, "ms": round(ms, 4), "Mpixels_per_s": round(wl.pixels / ms / 1e3, 1),
-                "GB_per_s": round(wl.bytes / ms / 1e6, 1), "frac_hbm": round(wl.bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                "note": "same job as `bench.py --gpus N` (workload c5), all images on this GPU"}
-            del wl
-        except Exception as e:  # never let a side measurement break the headline line
-            out["c5_%dx1080p" % args.c5_images] = {"error": repr(e)}
     # File path, PCIe inclusive (never the headline `value`): 1080p 4:2:0 baseline JPEG bytes in host
     # memory -> RGB bytes in host memory; host threads entropy-decode while the device works on
     # the previous chunk (jpeg_amd_decompress_batch).  The files come from this library's encoder.

@@ -240,6 +240,53 @@ __device__ __forceinline__ void idct_block_edge_cols(const uint32_t (&w)[32], QP
     }
 }
 
+// ---- the edge column of a block by (block, column) work-items ------------------------------------------------------------------
+// idct_block_edge_cols spends a whole wave pass on every block it is given; where a pass holds only a handful of blocks (the 8
+// neighbour blocks left and right of a 4:2:2 strip) 56 of 64 work-items idle through ~800 instructions.  Here EIGHT consecutive
+// lanes share one block: lane j of the group runs the first pass of ONE column -- k = edge_col_of_lane(j): dequantise + idct8
+// over the vertical frequency, the same 8 + 34 operations idct_block spends on that column -- and the second pass's outputs 0
+// and 7 of every row are formed ACROSS the eight lanes with three levels of DPP adds, in the reference's own association
+// (idct8<true>: e = level + f0; a0 = e + f4; b = f2 + f6; r0 = a0 + b; d1 = f1 + f7; d3 = f5 + f3; s0 = d1 + d3; g0 = r0 + s0;
+// g7 = r0 - s0 -- float addition is commutative, so which lane of a pair holds which operand does not matter):
+//     lanes j = 0..7 hold columns k = 0, 2, 1, 5, 4, 6, 7, 3
+//     level 1  lane j += lane j + 4   (row_shl:4)            lanes 0..3: a0, b, d1, d3
+//     level 2  lane j += lane j ^ 1   (quad_perm [1,0,3,2])  lane 0: r0, lane 2: s0
+//     level 3  lane 0 +- lane 2       (quad_perm [2,3,0,1])  lane 0: g0 or g7
+// ~130 instructions per wave for 8 blocks instead of ~810.  Lane 0 of each group ends up with the column; the other lanes'
+// results are by-products and must be ignored.
+__device__ __forceinline__ int edge_col_of_lane(int j) { return (int)((0x37645120u >> (4 * j)) & 7u); }
+
+__device__ __forceinline__ float dpp_f32(float v, int ctrl_row_shl4_quad1032_quad2301)
+{
+    const int i = __builtin_bit_cast(int, v);
+    int r;
+    if (ctrl_row_shl4_quad1032_quad2301 == 0) r = __builtin_amdgcn_update_dpp(i, i, 0x104, 0xf, 0xf, false);        // row_shl:4
+    else if (ctrl_row_shl4_quad1032_quad2301 == 1) r = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    else r = __builtin_amdgcn_update_dpp(i, i, 0x4E, 0xf, 0xf, false);                                             // quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, r);
+}
+
+// coef[h], q[h]: the quantised coefficients (k, h) and the modulated table entries q[8 h + k] of THIS lane's column k =
+// edge_col_of_lane(j), j = lane & 7; first: the block's column 0 is wanted (else column 7) -- uniform over the group.
+// edge[y]: sample (x = 0 or 7, row y) before the clamp, valid in the group's lane 0.
+__device__ __forceinline__ void idct_edge_col_split(const int (&coef)[8], const float (&q)[8], float level, bool first, int j,
+                                                    float (&edge)[8])
+{
+    float h[8], f[8];
+#pragma unroll
+    for (int hh = 0; hh < 8; ++hh) h[hh] = q[hh] * (float)coef[hh];
+    idct8<false>(h, 0.0f, f);                      // this lane's column after the first pass: f[y]
+    const float lv = j == 0 ? level : -0.0f;       // (-0) + f == f for every f, signed zeros included
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        float x = lv + f[y];                       // lane 0: e = level + f0
+        x = x + dpp_f32(x, 0);                     // a0 = e + f4 | b = f2 + f6 | d1 = f1 + f7 | d3 = f5 + f3
+        x = x + dpp_f32(x, 1);                     // r0 = a0 + b | . | s0 = d1 + d3 | .
+        const float s0 = dpp_f32(x, 2);
+        edge[y] = first ? x + s0 : x - s0;         // g0 = r0 + s0, g7 = r0 - s0
+    }
+}
+
 // Planar.Plane.load + fdct8x8 -- encode.swift:80-99, 191-196.
 // g[8*y + x]: samples already min(limit, Float(sample)); out H[8*h + k] before quantise.
 __device__ __forceinline__ void fdct_block(const float (&g)[64], float level, float (&H)[64])

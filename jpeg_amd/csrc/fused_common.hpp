@@ -123,12 +123,14 @@ __device__ __forceinline__ uint32_t lds_address(T *p)
 // The waiting side polls with plain LDS reads; what it reads from the tile after the poll has succeeded is issued, and
 // therefore performed, after the read that saw the counter.  Relaxed atomics + compiler barriers on purpose: a release /
 // acquire at workgroup scope would make hipcc wait with vmcnt(0) -- for the coefficient DMA in flight and for the pixel stores.
-// Call with all 64 lanes active: one lane adds, selected by narrowing EXEC around the ds_add (the compiler's form of
-// "if (lane == 0) atomicAdd" is a dozen instructions: compare, save EXEC, count the active lanes, multiply, restore).
+// One lane adds, selected by narrowing EXEC around the ds_add (the compiler's form of "if (lane == 0) atomicAdd" is a dozen
+// instructions: compare, save EXEC, count the active lanes, multiply, restore).  EXEC is saved and restored, not assumed:
+// the helper is correct from a divergent region as long as lane 0 is active there (every call site runs with all 64 lanes).
 __device__ __forceinline__ void lds_arrive(uint32_t *counter)
 {
     const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)counter;
-    asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(1u) : "memory");
+    uint64_t saved;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr), "v"(1u) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_peek(uint32_t *counter)
 {
@@ -160,6 +162,9 @@ __device__ __forceinline__ void lds_wait_ge_seen(uint32_t *counter, uint32_t tar
 // inside one asm statement, so nothing the compiler schedules can land between the two s_setreg; the f32 instructions
 // right before and right after the statement keep round-to-nearest (tools/probe_cvt_round2.hip).
 // c: 4 n floats, d: n dwords (byte i of d[k] = c[4 k + i]).
+// Precondition of every trunc_* helper: the wave runs in the default f32 rounding mode (round to nearest even, MODE[1:0] =
+// 0) -- the statement restores THAT, not a saved value (s_getreg + s_setreg_b32 would cost two more scalar slots per
+// pack; no kernel of this library ever leaves another mode set).
 #ifdef JA_X_NOSETREG   // experiment (wrong pixels): the packs without the two mode switches
 #define JA_RTZ_ON ""
 #define JA_RTZ_OFF ""

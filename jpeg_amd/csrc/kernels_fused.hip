@@ -241,6 +241,20 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         }
     };
 
+    // 4:2:2, second chroma pass ((block, column) work-items): where the eight coefficients of this lane's column lie in the
+    // DMA image of the 8 halo blocks (slot 8 b + i holds chunk i ^ ((b >> 1) & 7) of block b), fixed for the whole walk
+    uint32_t edge_off[8] = {};
+    int edge_k = 0;
+    if constexpr (IN422) {
+        const int b = lane0 >> 3;
+        edge_k = edge_col_of_lane(lane0 & 7);
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh) {
+            const int zz = zigzag_of(edge_k, hh);
+            edge_off[hh] = 16u * (8u * b + (uint32_t)((zz >> 3) ^ ((b >> 1) & 7))) + 2u * (zz & 7);
+        }
+    }
+
     // The wave's walk: strips first_tile + k, k = wave index, wave index + resident waves, ...
     const int nwaves = (int)gridDim.x * NW;   // the walk's stride
     FastDiv fd_nw; fd_nw.set((uint32_t)nwaves);
@@ -351,21 +365,30 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            read_block();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dma_strip(s, lane, 0);
-            // pass 2 (8 work-items): the neighbour blocks' edge columns -> the tile's halo dwords
+            // pass 2: the 8 neighbour blocks' edge columns -> the tile's halo dwords.  One (block, column) per work-item
+            // (idct_edge_col_split, dct.hpp): group b = lane >> 3 is block b of the buffer -- plane b >> 2, side (b >> 1) & 1
+            // (0 left, 1 right), block row b & 1 -- and lane j of the group its first-pass column edge_col_of_lane(j); the
+            // coefficients are read straight from the DMA image (16-bit LDS reads at offsets fixed before the walk).
             {
-                const int pl = (lane >> 2) & 1, side = (lane >> 1) & 1, r = lane & 1;
-                float g[64];
-                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
-                const bool exists = side ? 16 * sxi + 16 < (a.pw_c >> 3) : sxi > 0;
-                float edge[8];
-                uint32_t e[8];
+                const int b = lane >> 3, pl = b >> 2, side = (b >> 1) & 1, r = b & 1;
+                int cf[8];
+                float qv[8];
+                const char *cimg = reinterpret_cast<const char *>(coef_w);
+                const float *qcol = sqw[wave][1 + pl] + edge_k;
 #pragma unroll
-                for (int y = 0; y < 8; ++y) edge[y] = side ? g[8 * y] : g[8 * y + 7];
+                for (int hh = 0; hh < 8; ++hh) {
+                    cf[hh] = *reinterpret_cast<const int16_t *>(cimg + edge_off[hh]);
+                    qv[hh] = qcol[8 * hh];
+                }
+                // the block is in registers: the strip's luma blocks may follow it into the buffer
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma_strip(s, lane, 0);
+                float edge[8];
+                idct_edge_col_split(cf, qv, 128.5f, side != 0, lane & 7, edge);
+                uint32_t e[8];
                 trunc_bytes8(edge, e);
-                if (lane < 8 && exists) {
+                const bool exists = side ? 16 * sxi + 16 < (a.pw_c >> 3) : sxi > 0;
+                if ((lane & 7) == 0 && exists) {
                     uint32_t *dst = sc + pl * PLANE + 8 * r * PITCH + (side ? PITCH - 1 : 0);
 #pragma unroll
                     for (int y = 0; y < 8; ++y) dst[y * PITCH] = e[y] * 0x01010101u;

@@ -552,7 +552,9 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 #endif
             if (FAST && full) {
                 // chunk `lane` from every lane, chunk 64 + lane from lanes 0 .. 31: scalar row base + 32-bit lane offset, and
-                // the second store under a narrowed EXEC instead of a branch (this path runs with all 64 lanes active)
+                // the second store under a narrowed EXEC instead of a branch.  PRECONDITION: all 64 lanes active -- `FAST && full`
+                // is wave-uniform and this lambda is only called from the unconditional pixel-row loop, so EXEC is -1 here and
+                // is set back to -1, not to a saved copy (a save / restore pair would cost 16 scalar slots per strip)
                 const u32x4_t q0 = {pv0.x, pv0.y, pv0.z, pv0.w}, q1 = {pv1.x, pv1.y, pv1.z, pv1.w};
                 asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\t"
                              "s_mov_b64 exec, %5\n\t"

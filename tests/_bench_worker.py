@@ -44,25 +44,37 @@ class OracleWorkload:
     def device_name(self):
         return "cpu (oracle stand-in)"
 
+    def verify(self, quanta_np, image=0, threads=1):
+        """Same contract as bench.DecodeWorkload.verify: one image of the shard decoded again on its own and compared."""
+        i = self.first + image
+        again = W.decode(self.images[i % W.N_IMAGES], self.quanta)
+        return {"image_checked": image, "single_equals_batch": (again == self.digests[str(i)]) if self.n_images > 1 else None,
+                "parity_vs_oracle": again == self.digests[str(i)]}
+
 
 def main():
     rank, world, port, out, n = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import bench
     from jpeg_amd import dist as jd
-    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--c5-images", str(n), "--no-extras", "--no-cpu"]
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--c5-images", str(n), "--c5-steps", "2",
+                "--no-extras", "--no-cpu"]
     args = bench.parse()
-    made = []
+    made = {}
 
     def make(name, width, height, n_images, ring, quanta, seed):
-        assert (name, width, height) == ("c5", 1920, 1080)       # N > 1 defaults to the sharded C5 job
-        lo, hi = jd.shard(n, rank, world)
-        assert n_images == hi - lo
-        made.append(OracleWorkload(name, n_images, quanta, seed, lo))
-        return made[-1]
+        if name == "c3":     # the headline at every N: one image per rank per step (weak scaling)
+            assert (width, height, n_images) == (8192, 8192, 1)
+            made[name] = OracleWorkload(name, 1, quanta, seed, rank)
+        else:                # the collective C5 job leg: ONE job sharded over the ranks
+            assert (name, width, height) == ("c5", 1920, 1080)
+            lo, hi = jd.shard(n, rank, world)
+            assert n_images == hi - lo
+            made[name] = OracleWorkload(name, n_images, quanta, seed, lo)
+        return made[name]
 
     result = bench.run(args, make_workload=make, backend="gloo", device_kind="cpu")
-    json.dump({"rank": rank, "result": result, "digests": made[0].digests}, open(out, "w"))
+    json.dump({"rank": rank, "result": result, "digests": made["c5"].digests, "c3_digests": made["c3"].digests}, open(out, "w"))
 
 
 if __name__ == "__main__":

@@ -50,9 +50,10 @@ def test_two_ranks_gloo(tmp_path):
 
 
 def test_bench_two_ranks_gloo(tmp_path):
-    """bench.py's own N > 1 path (bench.run) under gloo, world size 2, the oracle standing in for the kernels:
-    the default workload at N > 1 is ONE sharded C5 job (strong scaling), every image is decoded by exactly one
-    rank, the line carries a per-rank record, and `value` is all ranks' pixels over the slowest rank's time."""
+    """bench.py's own N > 1 path (bench.run) under gloo, world size 2, the oracle standing in for the kernels.
+    `value` stays on ONE workload at every N (C3: an image per rank per step, weak scaling); the sharded C5 job is
+    measured collectively at every N and reported as extra.c5_<n>x1080p (strong scaling) -- every image decoded by
+    exactly one rank; every rank proves what it timed (per_rank[i].parity_vs_oracle) for both."""
     world, n = 2, 5
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -69,14 +70,26 @@ def test_bench_two_ranks_gloo(tmp_path):
     line = json.loads(lines[0])
     recs = [json.load(open(o)) for o in outs]
     assert recs[1]["result"] is None and recs[0]["result"] == line
-    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["steps"] == 2
-    assert line["config"]["images_per_step_all_ranks"] == n
+    # the headline: the same per-GPU work at every N
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["config"]["workload"].startswith("C3") and line["config"]["images_per_step_all_ranks"] == world
     assert [r["rank"] for r in line["per_rank"]] == [0, 1]
-    assert sum(r["images_per_step"] for r in line["per_rank"]) == n
+    assert all(r["images_per_step"] == 1 for r in line["per_rank"])
+    assert all(r["parity_vs_oracle"] is True for r in line["per_rank"]) and line["parity_vs_oracle"] is True
     slowest = max(r["wall_ms_per_step"] for r in line["per_rank"])
     assert abs(line["ms_per_step"] - slowest) < 1e-3 * slowest + 1e-3
-    px = W.SIZE[0] * W.SIZE[1] * n
+    px = W.SIZE[0] * W.SIZE[1] * world
     assert abs(line["value"] - px / (line["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * line["value"] + 0.1
+    assert "extra.c5_%dx1080p" % n in line["scaling_curve"]
+    # the sharded C5 job at this N: one record, all ranks, every rank self-checked
+    job = line["extra"]["c5_%dx1080p" % n]
+    assert job["n_gpus"] == world and job["scaling"] == "strong" and job["images"] == n and "error" not in job
+    assert [r["rank"] for r in job["per_rank"]] == [0, 1] and sum(r["images"] for r in job["per_rank"]) == n
+    assert all(r["parity_vs_oracle"] is True and r["single_equals_batch"] is True for r in job["per_rank"])
+    assert job["parity_vs_oracle"] is True
+    slowest = max(r["wall_ms_per_step"] for r in job["per_rank"])
+    assert abs(job["ms"] - slowest) < 1e-3 * slowest + 1e-3
+    assert abs(job["Mpixels_per_s"] - 1920 * 1080 * n / job["ms"] / 1e3) <= 0.01 * job["Mpixels_per_s"] + 0.1
     tables = W.tables()
     images = W.images()
     merged = {}

@@ -491,8 +491,6 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- chroma rows, produced just in time from the LDS tile ----
-        constexpr float inv = 1.0f / (float)((SX == 2 ? 4 : 1) * (SY == 2 ? 4 : 1));
-        constexpr float bias = MODE == 1 ? -127.5f : 0.5f;
         // Chroma row j of this block's patch: the LDS reads (hraw) and the conversion + horizontal
         // interpolation, x4 when SX == 2 (hconv), are separate so that the reads can be issued one pixel row
         // ahead of their use -- a wave that waits ~150 cycles for LDS ten times per strip leaves its SIMD to
@@ -507,11 +505,16 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 r[0] = row[2 * lbx]; r[1] = row[2 * lbx + 1]; r[2] = 0;
             }
         };
+        // 4:2:2 / 4:4:0: the samples enter as 2^15 + p + 1/32 (ubyte_magic, upsample.hpp) so that the ONE 3a + b step is exact
+        // (2^17 + v + 1/8) and its rounding needs no floor (finish)
         auto hconv = [&](const uint32_t (&r)[3], float (&o)[8]) {
             if constexpr (SX == 2) {
-                const float p[6] = {ubyte<3>(r[0]), ubyte<0>(r[1]), ubyte<1>(r[1]),
-                                    ubyte<2>(r[1]), ubyte<3>(r[1]), ubyte<0>(r[2])};
+                const float p[6] = {ubyte_magic<3>(r[0]), ubyte_magic<0>(r[1]), ubyte_magic<1>(r[1]),
+                                    ubyte_magic<2>(r[1]), ubyte_magic<3>(r[1]), ubyte_magic<0>(r[2])};
                 lerp_row_2x(p, o);
+            } else if constexpr (SY == 2) {
+                o[0] = ubyte_magic<0>(r[0]); o[1] = ubyte_magic<1>(r[0]); o[2] = ubyte_magic<2>(r[0]); o[3] = ubyte_magic<3>(r[0]);
+                o[4] = ubyte_magic<0>(r[1]); o[5] = ubyte_magic<1>(r[1]); o[6] = ubyte_magic<2>(r[1]); o[7] = ubyte_magic<3>(r[1]);
             } else {
                 o[0] = ubyte<0>(r[0]); o[1] = ubyte<1>(r[0]); o[2] = ubyte<2>(r[0]); o[3] = ubyte<3>(r[0]);
                 o[4] = ubyte<0>(r[1]); o[5] = ubyte<1>(r[1]); o[6] = ubyte<2>(r[1]); o[7] = ubyte<3>(r[1]);
@@ -522,10 +525,14 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             hraw(pl, j, r);
             hconv(r, o);
         };
-        // final chroma value of one pixel from the vertically combined sum v
+        // final chroma value of one pixel.  4:4:4: the sample itself [- 128].  One subsampled axis: floor(v / 4 + 1/2) [- 128] of
+        // v = 3a + b, without a floor -- V = 2^17 + v + 1/8 arrives exact, and fma(V, 1/4, 1.5 * 2^23 - 2^15 [- 128]) is ONE rounding of
+        // 1.5 * 2^23 [- 128] + v / 4 + 1/32 to a float whose ulp is 1; v / 4 + 1/32 is never half-way, and at v / 4 = n + 1/2 the 1/32
+        // tips it up like the reference's round-half-away (tests/test_colour_rounding.py enumerates every byte pair).  An FMA and a
+        // subtraction instead of an FMA and a v_floor_f32 (half rate): -128 slow instructions per strip.
         auto finish = [&](float v) -> float {
             if constexpr (SX == 1 && SY == 1) return MODE == 1 ? v - 128.0f : v;
-            else return floorf(__builtin_fmaf(v, inv, bias));
+            else return __builtin_fmaf(v, 0.25f, kMagic - 32768.0f - (MODE == 1 ? 128.0f : 0.0f)) - kMagic;
         };
 
         float hw[2][3][8];  // SY == 2: patch rows j-1, j, j+1 of both planes (sliding window)

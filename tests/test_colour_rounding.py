@@ -117,3 +117,30 @@ def test_floor_free_chroma_rounding_every_value():
         want = np.floor((v.astype(f32) * f32(1.0 / 16) + f32(-127.5 if sub128 else 0.5)).astype(f32)).astype(np.float64)  # the staged form
         assert np.array_equal(got, np.floor(v / 16 + 0.5) - (128 if sub128 else 0))
         assert np.array_equal(got, want)
+
+
+def test_floor_free_chroma_rounding_one_axis_every_byte_pair():
+    """k_luma_fused, 4:2:2 and 4:4:0 (one subsampled axis): bytes enter as 2^15 + p + 1/32, the single 3a + b step is exact and
+    ONE fma(., 1/4, C) rounds to floor(v / 4 + 1/2) [- 128] -- the value the staged form's floor(fma(v, 1/4, 1/2 [- 128])) and the
+    reference's round-half-away of (3a + b) / 4 give.  Every pair of bytes, both output modes."""
+    def fma(a, b, c):
+        return (a.astype(np.longdouble) * np.longdouble(b) + c.astype(np.longdouble)).astype(f32)
+
+    byte = np.arange(256, dtype=np.uint32)
+    P = ((np.uint32(0x47000008) | (byte << np.uint32(8))).astype(np.uint32)).view(f32)
+    pn, pf = np.meshgrid(P, P, indexing="ij")
+    bn, bf = np.meshgrid(byte.astype(np.float64), byte.astype(np.float64), indexing="ij")
+    v = (3 * bn + bf).ravel()
+    V = fma(pn.ravel(), 3.0, pf.ravel())
+    assert np.array_equal(V.astype(np.float64), 131072.0 + v + 0.125)
+    magic = f32(12582912.0)
+    for sub128 in (True, False):
+        C = f32(12582912.0 - 32768.0 - (128.0 if sub128 else 0.0))
+        got = (fma(V, f32(0.25), np.full_like(V, C)) - magic).astype(np.float64)
+        assert np.array_equal(got, np.floor(v / 4 + 0.5) - (128 if sub128 else 0))
+        staged = np.floor((v.astype(f32) * f32(0.25) + f32(-127.5 if sub128 else 0.5)).astype(f32)).astype(np.float64)
+        assert np.array_equal(got, staged)
+        # the reference: u0 * 0.75 + u1 * 0.25, rounded half away from zero (decode.swift:4250-4264), [- 128] at the colour stage
+        ref = np.floor(((bn.ravel().astype(f32) * f32(0.75)).astype(f32) + (bf.ravel().astype(f32) * f32(0.25)).astype(f32)).astype(f32).astype(np.float64) + 0.5)
+        assert np.array_equal(got, ref - (128 if sub128 else 0))
+

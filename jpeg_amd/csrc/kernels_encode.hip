@@ -217,10 +217,16 @@ __device__ __forceinline__ void wave_store_blocks_halves(const uint32_t (&w)[32]
 // would not fill the chip (a 4096 x 4096 frame is 512 tiles of 16 rows: two waves per SIMD, each of them bound by
 // its own instruction latency).
 template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN, int TY = ETY>
-__global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY == 1) ? 2 : 3)) void k_encode_fused(EncArgs a)
+// 4:2:2 / 4:4:0 (chroma pooled per half tile) are built for TWO waves per SIMD: at three (168 VGPRs) the register allocator
+// spills 9-19 registers of the FAST variants, and a spill reload waits with vmcnt(0) for every store in flight -- 4:4:0 at
+// 4096 x 4096 35.3 -> 30.0 us, 4:2:2 33.4 -> 33.0 (profiles/r04_ab_encode_perhalf_two_waves.txt)
+#ifndef JA_X_ENC_PERHALF_WAVES
+#define JA_X_ENC_PERHALF_WAVES 2
+#endif
+__global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY == 1) ? 2 : (CHROMA && SX * SY == 2) ? JA_X_ENC_PERHALF_WAVES : 3)) void k_encode_fused(EncArgs a)
 {
     // (waves per SIMD declared above: 4 for the 8-row tiles, 2 for 4:4:4 -- its 65 KiB of LDS and 256 VGPRs admit no
-    // more -- and 3 otherwise)
+    // more -- 2 for 4:2:2 / 4:4:0, and 3 for the 16-row tiles of the JA_X_ENC_TY experiment)
     constexpr bool HALFSTAGE = TY == 8;                  // 4 KiB of store staging per wave instead of 8
     static_assert(TY == 16 || (TY == 8 && SX * SY != 2), "the per-half chroma tiles of 4:2:2 / 4:4:0 need 16 block rows");
     constexpr bool INTHREAD = SX == 1 && SY == 1;        // 4:4:4: chroma block == the luma block's pixels
@@ -521,12 +527,19 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
                       L.width <= (1 << 23);
 #define JA_E(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_>), grid, dim3(kThreads), 0, stream, a)
 #define JA_E8(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_, 8>), grid, dim3(kThreads), 0, stream, a)
+    // (grey and 4:2:0 exist as 8-row tiles only: their 16-row instantiations -- 168 VGPRs with 8-14 of them spilled -- are
+    // built for the JA_X_ENC_TY experiment alone)
+#ifdef JA_X_ENC_TY
+#define JA_E16(SX_, SY_, RGB_, CH_, F_) JA_E(SX_, SY_, RGB_, CH_, F_)
+#else
+#define JA_E16(SX_, SY_, RGB_, CH_, F_) JA_E8(SX_, SY_, RGB_, CH_, F_)
+#endif
 #define JA_E2(RGB_, F_)                                         \
     do {                                                        \
         if (!chroma && ty == 8) JA_E8(1, 1, RGB_, false, F_);   \
-        else if (!chroma) JA_E(1, 1, RGB_, false, F_);          \
+        else if (!chroma) JA_E16(1, 1, RGB_, false, F_);        \
         else if (sx == 2 && sy == 2 && ty == 8) JA_E8(2, 2, RGB_, true, F_); \
-        else if (sx == 2 && sy == 2) JA_E(2, 2, RGB_, true, F_); \
+        else if (sx == 2 && sy == 2) JA_E16(2, 2, RGB_, true, F_); \
         else if (sx == 2 && sy == 1) JA_E(2, 1, RGB_, true, F_); \
         else if (sx == 1 && sy == 2) JA_E(1, 2, RGB_, true, F_); \
         else JA_E(1, 1, RGB_, true, F_);                        \
@@ -534,6 +547,7 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     if (rgb) { if (fast) JA_E2(true, true); else JA_E2(true, false); }
     else     { if (fast) JA_E2(false, true); else JA_E2(false, false); }
 #undef JA_E2
+#undef JA_E16
 #undef JA_E8
 #undef JA_E
     return hipGetLastError();

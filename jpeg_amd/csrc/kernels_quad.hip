@@ -77,7 +77,7 @@ template <int BX> struct QuadShape {
 
 // MODE: 0 = YCbCr bytes, 1 = RGB bytes.  FAST: W % 16 == 0 and 16-byte aligned rows, so every 16-byte chunk of a row
 // segment is entirely inside the image or entirely outside (no byte-wise tail code).
-template <int MODE, int BX, bool FAST>
+template <int MODE, int BX, bool FAST, bool DYN>
 __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 {
     constexpr int BY = QuadShape<BX>::BY, QS = QuadShape<BX>::QS;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
     // (512 x 1080p, static: the three generations end at 77 / 87 / 100 % of the call, profiles/r03_ab_generation_priority.txt);
     // with tickets the fast ones simply walk more stacks and everybody leaves together (-5 %).  Short walks keep the
     // static order: their last round is better planned than drawn (8192 x 8192, 5.33 trips: +5 % with tickets).
-    const bool dyn = a.tickets != nullptr;
+    constexpr bool dyn = DYN;   // the walk is a template parameter: each variant carries only its own branch and scalar state
     int cur = (int)blockIdx.x;
     const int last_round = a.nstacks - (int)gridDim.x, second_last_round = a.nstacks - 2 * (int)gridDim.x;
     int c_img, c_syi, c_sxi;   // the current trip's stack (located once, a trip ahead)
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 template <int MODE, int BX, bool FAST>
 int quad_resident_workgroups()
 {
-    return resident_workgroups_of(k_quad420<MODE, BX, FAST>, 2);
+    return resident_workgroups_of(k_quad420<MODE, BX, FAST, false>, 2);   // (the two walks of an instantiation have the same footprint)
 }
 
 template <int MODE, int BX, bool FAST>
@@ -645,7 +645,8 @@ hipError_t launch_quad(hipStream_t stream, const QuadArgs &a)
 #ifdef JA_PHASE_PROFILE   // development aid: JA_GRID_CAP=256 runs one workgroup per CU (a wave alone on its SIMD)
     if (const char *e = std::getenv("JA_GRID_CAP")) cap = std::min(cap, std::atoi(e));
 #endif
-    hipLaunchKernelGGL((k_quad420<MODE, BX, FAST>), dim3(std::min(a.nstacks, cap)), dim3(kThreads), 0, stream, a);
+    if (a.tickets) hipLaunchKernelGGL((k_quad420<MODE, BX, FAST, true>), dim3(std::min(a.nstacks, cap)), dim3(kThreads), 0, stream, a);
+    else hipLaunchKernelGGL((k_quad420<MODE, BX, FAST, false>), dim3(std::min(a.nstacks, cap)), dim3(kThreads), 0, stream, a);
     return hipGetLastError();
 }
 

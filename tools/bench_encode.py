@@ -45,3 +45,4 @@ run("RGB -> grey", {1: J.Component((1, 1), 0)}, "y8")
 run("RGB -> 4:2:0", {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)}, "ycc8")
 run("RGB -> 4:2:2", {1: J.Component((2, 1), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)}, "ycc8")
 run("RGB -> 4:4:4", {1: J.Component((1, 1), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)}, "ycc8")
+run("RGB -> 4:4:0", {1: J.Component((1, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)}, "ycc8")

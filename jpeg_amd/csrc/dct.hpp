@@ -134,6 +134,15 @@ __device__ __forceinline__ float coef_as_float(const uint32_t (&w)[32], int z)
     return (float)c;
 }
 
+// A modulated table stored TRANSPOSED in LDS (t[8 k + h]): the first pass reads the eight entries of one column k
+// (h = 0..7) together, and transposed they are 32 contiguous bytes = two ds_read_b128 instead of four ds_read2_b32.
+// Indexed like the natural table (q[8 h + k]), so idct_block & co. take it unchanged.
+struct TransposedTable {
+    const float *t;
+    __device__ __forceinline__ float operator[](int i) const { return t[8 * (i & 7) + (i >> 3)]; }
+    __device__ __forceinline__ TransposedTable operator+(int k) const = delete;
+};
+
 // Spectral.Plane.load + idct8x8 -- decode.swift:4020-4039, 4095-4099.
 // w: 64 int16 in zigzag order; q: modulated table, natural order q[8*h + k] (any address
 // space, uniform across the wave); g[8*y + x]: samples before clamp (level already added).

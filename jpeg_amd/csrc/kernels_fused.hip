@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     __shared__ __attribute__((aligned(16))) uint32_t coefbuf[NW][64 * 32];  // 8 KiB per wave
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     __shared__ uint32_t scw[NW][INTHREAD ? 1 : 2 * PLANE];  // chroma samples under the strip (+ halo); 4:4:4 keeps its own in registers
-    __shared__ float sqw[NW][NTAB][64];                  // modulated table(s): luma (, Cb, Cr)
+    __shared__ __attribute__((aligned(16))) float sqw[NW][NTAB][64];   // modulated table(s): luma (, Cb, Cr) -- TRANSPOSED ([8 k + h], dct.hpp TransposedTable)
 
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // strip math stays scalar
@@ -279,11 +279,11 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         // ---- modulated table (only when the image changes) ----
         if (img != img_of_table) {
             const int qk = lane & 7, qh = lane >> 3;
-            sq[lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi + zigzag_of(qk, qh)]);
+            sq[8 * qk + qh] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi + zigzag_of(qk, qh)]);
             if constexpr (INSTRIP) {
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    sqw[wave][1 + pl][lane] = modulate_entry(qk, qh, 0.125f,
+                    sqw[wave][1 + pl][8 * qk + qh] = modulate_entry(qk, qh, 0.125f,
                         a.quanta[img * a.quanta_stride + 64 * a.cqi[pl] + zigzag_of(qk, qh)]);
             }
             img_of_table = img;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 dma_strip(s, lane, pl == 0 ? 2 : 0);
                 float g[64];
-                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                idct_block(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, g);
                 {
                     uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
                     trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             {
                 const int pl = lane >> 5, r = (lane >> 4) & 1, c = lane & 15;
                 float g[64];
-                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                idct_block(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, g);
                 uint32_t *dst = sc + pl * PLANE + 8 * r * PITCH + 1 + 2 * c;
                 uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
                 trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
@@ -374,11 +374,11 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 int cf[8];
                 float qv[8];
                 const char *cimg = reinterpret_cast<const char *>(coef_w);
-                const float *qcol = sqw[wave][1 + pl] + edge_k;
+                const float *qcol = sqw[wave][1 + pl] + 8 * edge_k;   // transposed table: the column's eight entries are contiguous
 #pragma unroll
                 for (int hh = 0; hh < 8; ++hh) {
                     cf[hh] = *reinterpret_cast<const int16_t *>(cimg + edge_off[hh]);
-                    qv[hh] = qcol[8 * hh];
+                    qv[hh] = qcol[hh];
                 }
                 // the block is in registers: the strip's luma blocks may follow it into the buffer
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             {
                 const int pl = lane >> 5, r = (lane >> 4) & 1, c = lane & 15;
                 float g[64];
-                idct_block(w, sqw[wave][1 + pl], 128.5f, g);
+                idct_block(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, g);
                 uint32_t *dst = sc + pl * PLANE + (HY + 8 * r) * PITCH + 2 * c;
                 uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
                 trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 const bool below = lane >= 32;
                 const int pl = (lane >> 4) & 1, c = lane & 15;
                 float r8[8];
-                idct_block_edge_row(w, sqw[wave][1 + pl], 128.5f, !below, r8);
+                idct_block_edge_row(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, !below, r8);
                 uint32_t p01[2];
                 trunc_pack8(r8, p01);
                 if (below ? 2 * syi + 2 < uyc : syi > 0) {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
 #pragma unroll
         for (int i = 0; i < 64; ++i) yv[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff);
 #else
-        idct_block(w, sq, 128.5f, yv);
+        idct_block(w, TransposedTable{sq}, 128.5f, yv);
 #pragma unroll
         for (int i = 0; i < 64; ++i) yv[i] = floorf(__builtin_amdgcn_fmed3f(yv[i], 0.0f, 255.0f));
 #endif

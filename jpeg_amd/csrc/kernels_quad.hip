@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 #endif
     __shared__ __attribute__((aligned(16))) uint32_t stage[NW][BY * SEG_DW]; // one pixel row x BY block rows
     __shared__ uint32_t qt[2 * PLANE];                    // the stack's tile; row 0: halo above, rows 1 + CR p ...: strip p, last row: halo below
-    __shared__ float sqw[NW][3][64];                      // modulated tables: Y, Cb, Cr
+    __shared__ __attribute__((aligned(16))) float sqw[NW][3][64];   // modulated tables: Y, Cb, Cr -- TRANSPOSED ([8 k + h], dct.hpp TransposedTable)
     // two monotonic counters.  [0] "ready": a wave has written its samples of this trip into the tile;
     // [1] "done": a wave has read the last sample of this trip.
     __shared__ uint32_t next_slot[2];                     // dynamic walk: the stack of the next trip (wave 0 publishes it, double-buffered)
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
             const int qk = lane & 7, qh = lane >> 3;
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                sqw[qp][p][lane] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi[p] + zigzag_of(qk, qh)]);
+                sqw[qp][p][8 * qk + qh] = modulate_entry(qk, qh, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.qi[p] + zigzag_of(qk, qh)]);
             img_of_table = table_id;
         }
 
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 #pragma unroll
                 for (int i = 0; i < 64; ++i) g[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff) + sqw[qp][1 + pl][i];
 #else
-                idct_block(w, sqw[qp][1 + pl], 128.5f, g);
+                idct_block(w, TransposedTable{sqw[qp][1 + pl]}, 128.5f, g);
 #endif
                 uint32_t pk[16];
                 trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
             } else if (role == 2) {   // above: the block's last sample row; below: its first
                 const bool below = lane >= 2 * CBW;
                 float r[8];
-                idct_block_edge_row(w, sqw[qp][1 + pl], 128.5f, !below, r);
+                idct_block_edge_row(w, TransposedTable{sqw[qp][1 + pl]}, 128.5f, !below, r);
                 uint32_t p01[2];
                 trunc_pack8(r, p01);
                 const uint32_t p0 = p01[0], p1 = p01[1];
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
             } else {   // neighbour blocks: the column that touches the stack (first of the right, last of the left neighbour)
                 const int rowi = lane >> 2, side = lane & 1;
                 float c0[8], c7[8];
-                idct_block_edge_cols(w, sqw[qp][1 + pl], 128.5f, c0, c7);
+                idct_block_edge_cols(w, TransposedTable{sqw[qp][1 + pl]}, 128.5f, c0, c7);
                 uint32_t e[8];   // the edge sample of each row, replicated
                 {
                     float edge[8];
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 #pragma unroll
             for (int i = 0; i < 64; ++i) yv[i] = (float)(w[i & 31] >> (i & 32 ? 16 : 0) & 0xff);
 #else
-            idct_block(w, sqw[qp][0], 128.5f, yv);
+            idct_block(w, TransposedTable{sqw[qp][0]}, 128.5f, yv);
 #endif
             trunc_pack24(yv, ypk); trunc_pack24(yv + 24, ypk + 6); trunc_pack16(yv + 48, ypk + 12);
         }

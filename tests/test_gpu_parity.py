@@ -344,6 +344,28 @@ def test_fused_kernels_on_random_geometry(J, ctx, case):
         assert (a == b).all(), "encode differs"
 
 
+# 4:2:2: the neighbour blocks' edge columns are transformed by (block, column) work-items (idct_edge_col_split, dct.hpp): a
+# strip column without a left neighbour, without a right one, with both, a plane that ends inside the strip, two block rows
+# of which the second lies below the plane, extreme coefficients (the clamp), and every strip column of a wide image.
+@pytest.mark.parametrize("size", [(256, 16), (512, 16), (1024, 48), (272, 16), (768, 24), (4096, 32), (520, 40), (248, 8)])
+@pytest.mark.parametrize("rgb", [True, False])
+def test_422_edge_columns_by_block_and_column(J, ctx, size, rgb):
+    w, h = size
+    comps = [((2, 1), 0), ((1, 1), 1), ((1, 1), 1)]
+    layout, planes, quanta, q = _random_spectral(J, ctx, (w, h), comps, None, 8, 4220 + w + h)
+    rng = np.random.default_rng(w * 31 + h)
+    for p in planes[1:]:   # chroma: a third of the blocks with coefficients that drive the samples past both clamps
+        hot = rng.random(p.shape[:2]) < 0.33
+        p[hot] = rng.integers(-1024, 1024, (int(hot.sum()), 64)).astype(np.int16)
+    factors = [c.factor for c in layout.planes]
+    spectral = J.Spectral.from_host(ctx, (w, h), layout, planes, quanta, q=q)
+    color, unpack = (J.RGB, O.unpack_rgb8) if rgb else (J.YCbCr, O.unpack_ycc8)
+    got = spectral.decode(color).cpu().numpy()
+    _, rect = O.decode(planes, [quanta[i] for i in q], factors, (w, h))
+    want = unpack(rect, 3)
+    assert (got == want).all(), f"{(got != want).sum()} bytes differ"
+
+
 # ---- f-4: generic JPEG.Format plug-ins.  The ENCODE half at precision 12 / four planes is pinned on a
 # ---- reference-held vector: examples/custom-color's output.jpg + the dump of its input (tests/test_oracle_golden.py::
 # ---- test_twelve_bit_four_component_encode_pin for the oracle, tests/test_gpu_compress.py::test_twelve_bit_... for the

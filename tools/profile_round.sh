@@ -1,14 +1,14 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/profile_round.sh <tag>      e.g. r02
 # The round's committed evidence, for EVERY number bench.py reports:
-#   c3  bench.py --workload c3                (k_quad420<1, 32, true>, the headline)
-#   c5  bench.py --workload c5 (4096 x 1080p) (k_quad420<1, 16, true>: 16 x 4 strips, batch)
+#   c3  bench.py --workload c3                (k_quad420<1, 32, true, false>: the static walk, the headline)
+#   c5  bench.py --workload c5 (4096 x 1080p) (k_quad420<1, 32, true, true> + <1, 16, true, true>: the mixed cut, ticket walk)
 #   c2  tools/bench_idct.py --units 2048      (k_idct_plane: IDCT + dequant only, 2^22 blocks)
 #   c4  tools/bench_encode.py --only 4:2:0    (k_encode_fused, 4096 x 4096)
 # For each: rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes.
 # Output under gpurun_out/prof_<tag>/<cfg>/{kernel_stats.csv,pmc_fetch_size.csv,pmc_write_size.csv,run.log};
 # tools/make_traffic.py turns them into profiles/<tag>_traffic.json (+ profiles/traffic_latest.json for c3).
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$tag; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -23,8 +23,8 @@ run_cfg() {
   cp $O/$cfg/pw/pw_counter_collection.csv $O/$cfg/pmc_write_size.csv
   rm -rf $O/$cfg/kt $O/$cfg/pf $O/$cfg/pw
 }
-run_cfg c3 $R/bench.py --workload c3 --steps 50 --warmup 10 --no-extras --no-cpu --traffic none
-run_cfg c5 $R/bench.py --workload c5 --steps 5 --warmup 2 --no-extras --no-cpu --traffic none
+run_cfg c3 $R/bench.py --workload c3 --steps 50 --warmup 10 --no-extras --no-cpu --traffic none --no-c5-job --no-parity
+run_cfg c5 $R/bench.py --workload c5 --steps 5 --warmup 2 --no-extras --no-cpu --traffic none --no-parity
 run_cfg c2 $R/tools/bench_idct.py --units 2048 --only-main
 run_cfg c4 $R/tools/bench_encode.py --only 4:2:0
 cd $R

@@ -514,7 +514,7 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     const int need_y = chroma ? max(a.uy[0], sy * a.uy[1]) : a.uy[0];
     a.tiles_x = (need_x + ETX - 1) / ETX;
     // grey and 4:2:0 take the 8-row tiles (one luma block per work-item, four waves per SIMD): measured faster than the
-    // 16-row tiles at every size (tools/bench_encode.py, JPEG_AMD_ENC_TY=16 / 8: 4096 x 4096 4:2:0 30.9 -> 28.8 us, 8192 x 8192
+    // 16-row tiles at every size (tools/bench_encode.py, builds with -DJA_X_ENC_TY=16 / 8: 4096 x 4096 4:2:0 30.9 -> 28.8 us, 8192 x 8192
     // 103.6 -> 97.5, 2048 x 2048 23.3 -> 15.4, grey 4096 x 4096 21.2 -> 16.9).  4:2:2 / 4:4:0 pool chroma per half tile and
     // 4:4:4 parks it per lane: those keep 16 rows.
     const bool can8 = !chroma || (sx == 2 && sy == 2);

@@ -28,7 +28,8 @@
 // predicated stores, the reference's index clamps repaired in the tile), so any image size takes this kernel.
 //
 // Development switches (never defined in the product build): JA_PHASE_PROFILE, JA_X_NOSYNC, JA_X_NOCIDCT, JA_X_NOIDCT,
-// JA_X_NOSTORE, JA_X_STAGGER=<cycles>, JA_X_GRID_PER_CU=<1 | 2>.  (Round 3 also measured: the DMA instructions paced over the pixel rows or
+// JA_X_NOSTORE, JA_X_STAGGER=<cycles>, JA_X_GRID_PER_CU=<1 | 2>, JA_QUAD_WAVES=4 + JA_X_LDSHACK (round 4: what four waves per SIMD would be
+// worth -- pairs of waves share a coefficient buffer, wrong pixels; profiles/r04_ab_four_waves_per_simd.txt).  (Round 3 also measured: the DMA instructions paced over the pixel rows or
 // interleaved with the transform's columns, several priority schemes, progress feedback between the workgroups of a CU,
 // one chroma pass per strip instead of the roles -- profiles/r03_ab_*.txt; those variants are in git history or under
 // tools/exp_patches/, not in this file.)

@@ -24,6 +24,7 @@
 #pragma clang fp contract(off)
 
 #include "dct.hpp"
+#include "fused_common.hpp"   // trunc_pack16 (clamp + truncate + pack under round-toward-zero), kThreads
 #include "kernels.hpp"
 
 #include <cstdlib>
@@ -33,7 +34,6 @@ namespace jpeg_amd {
 
 namespace {
 
-constexpr int kThreads = 256;
 constexpr int ETX = 32;  // luma blocks per tile row
 constexpr int ETY = 16;  // luma blocks per tile column (8 for the small-image variant, template parameter TY)
 
@@ -60,11 +60,15 @@ __device__ __forceinline__ float ubyte(uint32_t v)
 // The two products by 0.5 are exact (r, b are bytes), so `x + 0.5 b` and `128 + 0.5 r` round once either way: those two
 // steps are one FMA each.  No other step may be fused: every other FMA placement changes some of the 2^24 results
 // (tests/test_colour_rounding.py enumerates them).
+// RAWC: Cb / Cr are returned BEFORE their truncation (they lie in [0.5, 255.5]): the 4:2:0 pooling truncates them itself, four
+// at a time, with the saturating convert under round-toward-zero.
+template <bool RAWC = false>
 __device__ __forceinline__ void rgb_to_ycc(float r, float g, float b, float &y, float &cb, float &cr)
 {
     y  = floorf((0.2990f * r + 0.5870f * g) + 0.1140f * b);          // `0 + x` is exact
-    cb = floorf(__builtin_fmaf(0.5000f, b, (128.0f + -0.1687f * r) + -0.3313f * g));
-    cr = floorf((__builtin_fmaf(0.5000f, r, 128.0f) + -0.4187f * g) + -0.0813f * b);
+    cb = __builtin_fmaf(0.5000f, b, (128.0f + -0.1687f * r) + -0.3313f * g);
+    cr = (__builtin_fmaf(0.5000f, r, 128.0f) + -0.4187f * g) + -0.0813f * b;
+    if constexpr (!RAWC) { cb = floorf(cb); cr = floorf(cr); }
 }
 
 // horizontal frequency k of the coefficient at zigzag index z (inverse of zigzag_of over k), tabulated at compile time
@@ -216,7 +220,8 @@ __device__ __forceinline__ void wave_store_blocks_halves(const uint32_t (&w)[32]
 // block, and half of the work-items a chroma block -- twice as many workgroups, for images whose 16-row tiles
 // would not fill the chip (a 4096 x 4096 frame is 512 tiles of 16 rows: two waves per SIMD, each of them bound by
 // its own instruction latency).
-template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN, int TY = ETY>
+// POOLI: 4:2:0 only -- the 2 x 2 box filter in the integer domain (launches of several rounds; see POOL_INT below).
+template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN, int TY = ETY, bool POOLI = false>
 // 4:2:2 / 4:4:0 (chroma pooled per half tile) are built for TWO waves per SIMD: at three (168 VGPRs) the register allocator
 // spills 9-19 registers of the FAST variants, and a spill reload waits with vmcnt(0) for every store in flight -- 4:4:0 at
 // 4096 x 4096 35.3 -> 30.0 us, 4:2:2 33.4 -> 33.0 (profiles/r04_ab_encode_perhalf_two_waves.txt)
@@ -230,6 +235,12 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
     constexpr bool HALFSTAGE = TY == 8;                  // 4 KiB of store staging per wave instead of 8
     static_assert(TY == 16 || (TY == 8 && SX * SY != 2), "the per-half chroma tiles of 4:2:2 / 4:4:0 need 16 block rows");
     constexpr bool INTHREAD = SX == 1 && SY == 1;        // 4:4:4: chroma block == the luma block's pixels
+    // 4:2:0: the 2 x 2 box filter in the integer domain (POOLI) removes 1.6 of the 50 instructions per pixel.  It pays where the
+    // launch is several rounds of workgroups long (8192 x 8192: 88.6 against 91.5 us) and LOSES where the whole frame is one
+    // round (4096 x 4096: 24.7 against 23.8 us -- every workgroup in the same phase, and the dependent convert / dot / permute
+    // chain is longer than the float sum it replaces): the launcher picks (profiles/r04_ab_encode_integer_pooling.txt).
+    static_assert(!POOLI || (CHROMA && SX == 2 && SY == 2), "integer pooling is the 4:2:0 box filter");
+    constexpr bool POOL_INT = POOLI;
     // 4:2:2 / 4:4:0: the 8 luma block rows of one `half` already hold 256 chroma blocks (one per
     // work-item), so the chroma tile covers one half at a time and stays at 16 KiB
     constexpr bool PERHALF = CHROMA && SX * SY == 2;
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
                 float yy, cb, cr;
-                if constexpr (RGB) rgb_to_ycc(c0[x], c1[x], c2[x], yy, cb, cr);
+                if constexpr (RGB) rgb_to_ycc<POOL_INT>(c0[x], c1[x], c2[x], yy, cb, cr);
                 else { yy = c0[x]; cb = c1[x]; cr = c2[x]; }
                 yv[8 * y + x] = yy;
                 crow[0][y & 1][x] = cb;
@@ -345,6 +356,26 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) {
                         uint32_t packed[(8 / SX + 3) / 4] = {};
+                        if constexpr (POOL_INT) {
+                            // 4:2:0 (round 4): the window's four samples are truncated INTO ONE DWORD (v_cvt_pk_u8_f32 under
+                            // round-toward-zero: floor for these positive values, encode.swift's per-pixel UInt8 conversion),
+                            // summed by ONE v_dot4_u32_u8 with the weights 64, 64, 64, 64 -- 64 * sum < 2^16, so byte 1 of the
+                            // result IS sum >> 2 = trunc(Float(sum) / 4) (encode.swift:419-421) -- and three v_perm_b32 gather
+                            // the four results.  23 instructions per plane and pair of rows instead of 36.
+                            float f[16];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                f[4 * i + 0] = crow[pl][0][2 * i]; f[4 * i + 1] = crow[pl][0][2 * i + 1];
+                                f[4 * i + 2] = crow[pl][1][2 * i]; f[4 * i + 3] = crow[pl][1][2 * i + 1];
+                            }
+                            uint32_t q4[4], sum64[4];
+                            trunc_pack16(f, q4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sum64[i] = __builtin_amdgcn_udot4(q4[i], 0x40404040u, 0u, false);
+                            const uint32_t lo = __builtin_amdgcn_perm(sum64[1], sum64[0], 0x0c0c0501u);   // bytes: s0.b1, s1.b1, 0, 0
+                            const uint32_t hi = __builtin_amdgcn_perm(sum64[3], sum64[2], 0x0c0c0501u);
+                            packed[0] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                        } else
 #pragma unroll
                         for (int i = 0; i < 8 / SX; ++i) {
                             float sum;
@@ -522,11 +553,16 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     const int tiles_y = (need_y + ty - 1) / ty;
     if (a.tiles_x * tiles_y == 0 || n_images == 0) return hipSuccess;
     const dim3 grid(a.tiles_x * tiles_y, n_images);
+    // more workgroups than are resident at once (four 8-row tiles per CU)?  Then the launch is several rounds long.
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const bool several_rounds = (long)a.tiles_x * tiles_y * n_images > 4L * cus;
     // (the vector-load path addresses a tile's rows with 32-bit byte offsets: 16 block rows x 8 x W x 3 B must stay below 2^32)
     const bool fast = (L.width & 7) == 0 && (pixel_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 7) == 0 &&
                       L.width <= (1 << 23);
 #define JA_E(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_>), grid, dim3(kThreads), 0, stream, a)
 #define JA_E8(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_, 8>), grid, dim3(kThreads), 0, stream, a)
+#define JA_E8I(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_, 8, true>), grid, dim3(kThreads), 0, stream, a)
     // (grey and 4:2:0 exist as 8-row tiles only: their 16-row instantiations -- 168 VGPRs with 8-14 of them spilled -- are
     // built for the JA_X_ENC_TY experiment alone)
 #ifdef JA_X_ENC_TY
@@ -538,6 +574,7 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     do {                                                        \
         if (!chroma && ty == 8) JA_E8(1, 1, RGB_, false, F_);   \
         else if (!chroma) JA_E16(1, 1, RGB_, false, F_);        \
+        else if (sx == 2 && sy == 2 && ty == 8 && several_rounds) JA_E8I(2, 2, RGB_, true, F_); \
         else if (sx == 2 && sy == 2 && ty == 8) JA_E8(2, 2, RGB_, true, F_); \
         else if (sx == 2 && sy == 2) JA_E16(2, 2, RGB_, true, F_); \
         else if (sx == 2 && sy == 1) JA_E(2, 1, RGB_, true, F_); \
@@ -548,6 +585,7 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     else     { if (fast) JA_E2(false, true); else JA_E2(false, false); }
 #undef JA_E2
 #undef JA_E16
+#undef JA_E8I
 #undef JA_E8
 #undef JA_E
     return hipGetLastError();

@@ -144,3 +144,19 @@ def test_floor_free_chroma_rounding_one_axis_every_byte_pair():
         ref = np.floor(((bn.ravel().astype(f32) * f32(0.75)).astype(f32) + (bf.ravel().astype(f32) * f32(0.25)).astype(f32)).astype(f32).astype(np.float64) + 0.5)
         assert np.array_equal(got, ref - (128 if sub128 else 0))
 
+
+def test_integer_box_filter_of_the_420_encode():
+    """k_encode_fused (4:2:0, round 4): four truncated bytes in one dword, ONE v_dot4_u32_u8 with the weights 64, 64, 64, 64, and
+    byte 1 of the result is trunc(Float(sum) / 4) (encode.swift:419-421): every sum, and the truncation of every Cb / Cr the
+    colour matrix can produce (they lie in [0.5, 255.5], so truncation toward zero IS the reference's clamp + UInt8 conversion)."""
+    s = np.arange(0, 4 * 255 + 1, dtype=np.int64)
+    assert (64 * s).max() < 1 << 16
+    assert np.array_equal(((64 * s) >> 8) & 0xff, (s.astype(f32) / f32(4)).astype(np.int64))
+    r, g, b = np.meshgrid(np.arange(256, dtype=f32), np.arange(256, dtype=f32), np.arange(256, dtype=f32), indexing="ij")
+    def fma(a, x, c):
+        return (np.longdouble(a) * x.astype(np.longdouble) + c.astype(np.longdouble)).astype(f32)
+    cb = fma(f32(0.5), b, ((f32(128.0) + f32(-0.1687) * r).astype(f32) + (f32(-0.3313) * g).astype(f32)).astype(f32))
+    cr = ((fma(f32(0.5), r, np.full_like(r, f32(128.0))) + (f32(-0.4187) * g).astype(f32)).astype(f32) + (f32(-0.0813) * b).astype(f32)).astype(f32)
+    for c in (cb, cr):
+        assert c.min() >= 0.5 and c.max() <= 255.5      # positive: truncation == floor == clamp + truncate
+

@@ -71,6 +71,36 @@ def test_config4_4096x4096_encode(env):
         assert (c.cpu().numpy().reshape(w.shape) == w).all()
 
 
+@pytest.mark.parametrize("size,n,ycc", [((8192, 2176), 1, False), ((640, 472), 52, False), ((1920, 1080), 9, True)], ids=lambda v: str(v))
+def test_420_encode_of_several_rounds_integer_box_filter(env, size, n, ycc):
+    """Launches of more workgroups than are resident at once take the 4:2:0 encode kernel whose 2 x 2 box filter runs in the
+    integer domain (k_encode_fused<..., POOLI = true>, round 4; one-round launches like config 4 keep the float form): one large
+    frame and two batches (RGB and YCbCr input, ragged sizes), every coefficient against the oracle."""
+    e = env
+    torch, _lib = e["torch"], e["_lib"]
+    w, h = size
+    dev = e["ctx"].torch_device
+    g = torch.Generator(device=dev); g.manual_seed(w + h + n)
+    px = torch.randint(0, 256, (n, h * w * 3), dtype=torch.uint8, device=dev, generator=g)
+    px[:, : (h * w * 3) // 2] //= 3     # a dark half: the box filter sees small and large sums
+    units = e["layout"].units(size)
+    L = e["layout"].c_layout(size, units, [0, 1, 1])
+    coefs = [torch.empty((n, 64 * a * b), dtype=torch.int16, device=dev) for a, b in units]
+    st = e["lib"].jpeg_amd_encode_batch(e["ctx"].handle, C.byref(L), n, px.data_ptr(), h * w * 3, _lib.COLOR_YCC8 if ycc else _lib.COLOR_RGB8,
+                                       e["d_q"].data_ptr(), 0, 2, _lib.ptr_array([c.data_ptr() for c in coefs]),
+                                       _lib.size_array([64 * a * b for a, b in units]))
+    assert st == 0
+    for i in sorted({0, n // 2, n - 1}):
+        pix = px[i].cpu().numpy().reshape(-1, 3)
+        if ycc:
+            planar = O.decompose(O.pack_ycc8(pix, 3).reshape(h, w, 3), size, FACTORS, (2, 2))
+            want = [O.fdct_plane(p, q) for p, q in zip(planar, [e["q"][0], e["q"][1], e["q"][1]])]
+        else:
+            want = O.encode(pix, size, FACTORS, [e["q"][0], e["q"][1], e["q"][1]], threads=THREADS)
+        for c, wnt in zip(coefs, want):
+            assert (c[i].cpu().numpy().reshape(wnt.shape) == wnt).all(), f"image {i}"
+
+
 @pytest.mark.parametrize("size,n", [((2048, 64), 1), ((2048, 128), 1), ((4096, 192), 1), ((2048, 1024), 2), ((2048, 128), 5), ((6144, 64), 3),
                                     ((512, 256), 9), ((256, 64), 40), ((1280, 1016), 2), ((768, 1000), 3),
                                     ((2048, 96), 2), ((512, 112), 7), ((3840, 2160), 1), ((256, 32), 9), ((768, 480), 3)],

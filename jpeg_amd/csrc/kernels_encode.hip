@@ -20,7 +20,10 @@
 //   - Float(sum) / Float(n) truncated, n in {1, 2, 4}, is floor(sum * (1/n)) exactly.
 //
 // Development switches (tools/build_exp.sh, never in the product build): JA_X_ENC_NOSTORE,
-// JA_X_ENC_L2LOAD -- the kernel without its stores / with every load hitting L2.
+// JA_X_ENC_L2LOAD -- the kernel without its stores / with every load hitting L2; JA_X_ENC_NOCHROMA -- without the two-wave
+// chroma tail of a tile (round 4: 23.6 -> 19.3 us at 4096 x 4096, 86.1 -> 68.7 at 8192 x 8192: the tail's share of the
+// tile's instructions, 18 %, is its share of the time -- the kernel is bound by the instructions it issues in all, not by
+// the longest wave); JA_X_ENC_TY, JA_X_ENC_PERHALF_WAVES.
 #pragma clang fp contract(off)
 
 #include "dct.hpp"
@@ -489,6 +492,9 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
     if constexpr (CHROMA && !INTHREAD && !PERHALF) {
         __syncthreads();
         __builtin_amdgcn_s_setprio(2);   // the tile's tail; the waves that are still converting and transforming luma go first
+#ifdef JA_X_ENC_NOCHROMA   // experiment (no chroma coefficients): what does the two-wave chroma tail of a tile cost?
+        if (a.W < 0)
+#endif
         chroma_blocks(0);
     }
 

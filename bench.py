@@ -331,6 +331,13 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
     if dist is not None:
         assert (d_quanta.cpu().numpy().view(np.uint16) == q_np).all()
 
+    if not args.no_parity:
+        # the checker (oracle/: a C restatement built with gcc) is compiled by ONE rank; the others load the finished library
+        if rank == 0:
+            from oracle import oracle as _O
+            _O.build()
+        barrier()
+
     workload = args.workload if args.workload != "auto" else "c3"   # ONE workload under `value` at every N
     check_threads = max(1, min(64, (os.cpu_count() or 1) // world))
     if make_workload is None:

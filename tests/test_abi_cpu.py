@@ -41,6 +41,23 @@ def test_swift_module_header_is_the_generated_copy():
     assert a == b, "run `python -m jpeg_amd.build` (it regenerates the Swift module's header from include/jpeg_amd.h)"
 
 
+def test_build_refuses_a_spilling_decode_kernel():
+    """jpeg_amd/build.py parses hipcc's kernel-resource-usage remarks of kernels_quad.hip / kernels_fused.hip and fails the
+    build when k_quad420 / k_luma_fused touch scratch memory (they count their own VM operations: `s_waitcnt vmcnt(16)`)."""
+    from jpeg_amd import build as B
+    ok = ("x.hip:1:1: remark: Function Name: _ZN8jpeg_amd9k_quad420ILi1EEEv [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.hip:1:1: remark:     VGPRs: 137 [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.hip:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+          "x.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n")
+    B.check_no_scratch("x.hip", ok, "k_quad420")
+    with pytest.raises(RuntimeError, match="must not spill"):
+        B.check_no_scratch("x.hip", ok.replace("VGPRs Spill: 0", "VGPRs Spill: 7").replace("bytes/lane]: 0", "bytes/lane]: 32"), "k_quad420")
+    with pytest.raises(RuntimeError, match="cannot see"):
+        B.check_no_scratch("x.hip", ok, "k_luma_fused")     # no remark for the kernel: the gate must not pass silently
+    other = ok.replace("k_quad420", "k_other").replace("VGPRs Spill: 0", "VGPRs Spill: 9")
+    B.check_no_scratch("x.hip", ok + other, "k_quad420")     # another kernel of the file may spill (the edge paths of the encoder do)
+
+
 def test_version_and_strerror():
     L = _lib.lib()
     assert L.jpeg_amd_version() == 100

@@ -90,19 +90,21 @@ __device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32
 }
 
 // Resident workgroups of a persistent kernel on the CURRENT device: workgroups per CU (what the occupancy query says for this
-// instantiation) x CUs.  One cache per instantiation (TAG = the kernel's type) and per device, filled once under
-// std::call_once: contexts of several devices, and first calls from several host threads, see their own device's value.
+// instantiation) x CUs.  One cache per KERNEL -- the kernel's address is the template argument: all instantiations of a
+// kernel template share one function TYPE, so a cache keyed by type would hand the first instantiation's answer to all of
+// them -- and per device, filled once under std::call_once: contexts of several devices, and first calls from several host
+// threads, see their own device's value.
 constexpr int kMaxDevices = 64;
-template <typename Kernel>
-inline int resident_workgroups_of(Kernel kernel, int fallback_per_cu)
+template <auto Kernel>
+inline int resident_workgroups_of(int fallback_per_cu)
 {
     struct PerDevice { std::once_flag once; int value = 0; };
-    static PerDevice cache[kMaxDevices];   // one array per Kernel type, i.e. per instantiation
+    static PerDevice cache[kMaxDevices];   // one array per kernel instantiation
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     auto query = [&]() {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = fallback_per_cu;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = fallback_per_cu;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         return per_cu * cus;
     };

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
 template <int SX, int SY, int MODE, bool CHROMA, bool FAST, int BX>
 int resident_workgroups()
 {
-    return resident_workgroups_of(k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX>, 2);
+    return resident_workgroups_of<k_luma_fused<SX, SY, MODE, CHROMA, FAST, BX>>(2);
 }
 
 template <int MODE, bool FAST, int BX>

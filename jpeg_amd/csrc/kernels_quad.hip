@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 template <int MODE, int BX, bool FAST>
 int quad_resident_workgroups()
 {
-    return resident_workgroups_of(k_quad420<MODE, BX, FAST, false>, 2);   // (the two walks of an instantiation have the same footprint)
+    return resident_workgroups_of<k_quad420<MODE, BX, FAST, false>>(2);   // (the two walks of an instantiation have the same footprint)
 }
 
 template <int MODE, int BX, bool FAST>

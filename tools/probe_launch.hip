@@ -40,6 +40,29 @@ void run(const char *name, int grid, unsigned long long *d_t, float *d_sink)
     printf("%-44s grid %4d x %4d: start of a wave mean %5.2f us, last %5.2f us (mean of %d launches)\n", name, grid, THREADS, mean_acc / reps, max_acc / reps, reps);
 }
 
+// the same grid as TWO launches on two streams (half the workgroups each), issued back to back: does a second hardware queue
+// halve the ramp?
+template <int THREADS, int LDS_DWORDS>
+void run_two_streams(const char *name, int grid, unsigned long long *d_t, float *d_sink)
+{
+    hipStream_t s1, s2; (void)hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    const int waves = grid * THREADS / 64, half = grid / 2;
+    std::vector<unsigned long long> h(waves);
+    double mean_acc = 0, max_acc = 0;
+    const int reps = 20;
+    for (int r = 0; r < reps + 2; ++r) {
+        hipLaunchKernelGGL((k_start<THREADS, LDS_DWORDS>), dim3(half), dim3(THREADS), 0, s1, d_t, d_sink);
+        hipLaunchKernelGGL((k_start<THREADS, LDS_DWORDS>), dim3(grid - half), dim3(THREADS), 0, s2, d_t + (size_t)half * THREADS / 64, d_sink);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), d_t, waves * 8, hipMemcpyDeviceToHost);
+        const unsigned long long t0 = *std::min_element(h.begin(), h.end());
+        double m = 0, mx = 0;
+        for (auto v : h) { m += (double)(v - t0); mx = std::max(mx, (double)(v - t0)); }
+        if (r >= 2) { mean_acc += m / waves / 100.0; max_acc += mx / 100.0; }
+    }
+    printf("%-44s grid 2 x %4d x %4d: start of a wave mean %5.2f us, last %5.2f us (mean of %d launches)\n", name, half, THREADS, mean_acc / reps, max_acc / reps, reps);
+}
+
 int main()
 {
     unsigned long long *d_t; float *d_sink;
@@ -49,5 +72,8 @@ int main()
     run<512, 19200>("2 workgroups per CU (512 threads, 77 KB LDS)", 512, d_t, d_sink);
     run<256, 256>("3 per CU, no LDS to speak of", 768, d_t, d_sink);
     run<1024, 38400>("1 per CU, 1024 threads, 153 KB", 256, d_t, d_sink);
+    run_two_streams<256, 12800>("3 per CU as two launches on two streams", 768, d_t, d_sink);
+    run<256, 6400>("4 per CU (256 threads, 25 KB: the encode)", 1024, d_t, d_sink);
+    run_two_streams<256, 6400>("4 per CU as two launches on two streams", 1024, d_t, d_sink);
     return 0;
 }

@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="auto", choices=["auto", "c3", "c5"],
                     help="auto = c3 at every N (weak scaling, the headline); c5: the sharded 4096 x 1080p job as the headline")
+    ap.add_argument("--dist", action="store_true",
+                    help="initialise torch.distributed also at N = 1 (RCCL world of one: the table broadcast and the max over ranks then run as real collectives)")
     ap.add_argument("--no-c5-job", action="store_true", help="skip the collective C5 job leg (extra.c5_<n>x1080p)")
     ap.add_argument("--c5-steps", type=int, default=5)
     ap.add_argument("--no-parity", action="store_true", help="skip the per-rank comparison with the CPU oracle")
@@ -144,17 +146,27 @@ class DecodeWorkload:
         return planes, self.out[image].cpu().numpy().reshape(-1, 3)
 
 
-def time_region(wl, fn, steps, sync, barrier):
+def time_region(wl, fn, steps, sync, barrier, errors=None):
     """Barrier + synchronize on both sides; returns (wall seconds, device-event ms: HIP events on the stream the
-    kernels are launched on, via the workload's timer)."""
+    kernels are launched on, via the workload's timer).  With `errors` (a list) an exception of the local work is
+    recorded there instead of being raised, and the rank STILL meets both barriers: the collective sequence of a
+    measurement is the same on every rank whatever happens to one of them."""
     barrier()
     sync()
     t0 = time.perf_counter()
-    wl.timer_begin()
-    for _ in range(steps):
-        fn()
-    gpu_ms = wl.timer_end()
-    sync()
+    gpu_ms = float("nan")
+    try:
+        if wl is not None:
+            wl.timer_begin()
+        for _ in range(steps):
+            fn()
+        if wl is not None:
+            gpu_ms = wl.timer_end()
+        sync()
+    except Exception as e:
+        if errors is None:
+            raise
+        errors.append(repr(e)[:200])
     barrier()
     return time.perf_counter() - t0, gpu_ms
 
@@ -306,9 +318,10 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
         dev = torch.device("cpu")
 
     dist = None
-    if world > 1:
+    if world > 1 or getattr(args, "dist", False):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if device_kind == "cuda":
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
         else:
@@ -539,26 +552,35 @@ def run_c5_job(args, make_workload, d_quanta, q_np, rank, world, dev, dist, sync
     from jpeg_amd import dist as jd
     lo, hi = jd.shard(args.c5_images, rank, world)
     rec = {"rank": rank, "images": hi - lo}
+    # Local work may fail on one rank (e.g. out of memory on a 25-51 GB shard); the COLLECTIVE sequence below -- the two
+    # barriers of time_region, max_over_ranks, all_gather_object -- is unconditional, so that a failing rank produces an
+    # "error" record instead of pairing its collectives with the wrong ones of the healthy ranks.
+    errors, wl = [], None
     try:
         wl = make_workload("c5", 1920, 1080, hi - lo, 1, d_quanta, 20240807 + lo) if hi > lo else None
-        step = wl.step if wl is not None else (lambda: None)
-        step()
+        if wl is not None:
+            wl.step()
         sync()
-        if wl is not None:
-            wall, gpu_ms = time_region(wl, step, args.c5_steps, sync, barrier)
+    except Exception as e:
+        errors.append(repr(e)[:200])
+        wl = None
+    step = wl.step if wl is not None else (lambda: None)
+    wall, gpu_ms = time_region(wl, step, args.c5_steps, sync, barrier, errors)
+    pixels_all, bytes_all = 1920 * 1080 * args.c5_images, None
+    if wl is not None and not errors:
+        try:
             rec["gpu_ms_per_step"] = round(gpu_ms / args.c5_steps, 4)
-        else:   # more ranks than images: keep the barriers of time_region
-            barrier(); sync(); t0 = time.perf_counter(); sync(); barrier(); wall = time.perf_counter() - t0
-        rec["wall_ms_per_step"] = round(wall / args.c5_steps * 1e3, 4)
-        if wl is not None and not args.no_parity:
-            rec.update(wl.verify(q_np, image=(hi - lo - 1) // 2, threads=check_threads))
-        pixels_all, bytes_all = 1920 * 1080 * args.c5_images, None
-        if wl is not None:
+            if not args.no_parity:
+                rec.update(wl.verify(q_np, image=(hi - lo - 1) // 2, threads=check_threads))
             bytes_all = wl.bytes // (hi - lo) * args.c5_images
-        del wl
-    except Exception as e:   # a side measurement must not take the bench line with it -- but every rank must still meet the collectives
-        rec["error"] = repr(e)[:200]
-        wall, pixels_all, bytes_all = float("inf"), 1920 * 1080 * args.c5_images, None
+        except Exception as e:
+            errors.append(repr(e)[:200])
+    del wl
+    if errors:
+        rec["error"] = "; ".join(errors)
+        wall = float("inf")
+    else:
+        rec["wall_ms_per_step"] = round(wall / args.c5_steps * 1e3, 4)
     wall_max = jd.max_over_ranks(wall if wall != float("inf") else 1e30, dev, dist)
     recs = [rec]
     if dist is not None:

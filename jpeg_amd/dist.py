@@ -27,7 +27,7 @@ def broadcast_quanta(quanta, src: int, device, dist=None):
     else:
         q = np.ascontiguousarray(np.asarray(quanta, np.uint16).reshape(-1, 64))
         t = torch.from_numpy(q.view(np.int16).copy()).to(device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():   # (also a world of one: the collective then runs on the one rank)
         # neither gloo nor NCCL/RCCL has a 16-bit integer type: ship the 128-byte tables as int32
         dist.broadcast(t.view(torch.int32), src=src)
     return t
@@ -36,7 +36,7 @@ def broadcast_quanta(quanta, src: int, device, dist=None):
 def max_over_ranks(value: float, device, dist=None) -> float:
     import torch
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

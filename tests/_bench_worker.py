@@ -2,7 +2,8 @@
 (bench.run: sharding with jpeg_amd.dist.shard, table broadcast, barrier + max-over-ranks timing, per-rank records)
 under gloo on CPU.  The oracle stands in for the kernels (allowed in tests): the workload object below has the
 interface of bench.DecodeWorkload but decodes tiny images on the host.
-usage: python _bench_worker.py <rank> <world> <port> <out.json> <c5_images>"""
+usage: python _bench_worker.py <rank> <world> <port> <out.json> <c5_images> [fail-rank]
+(fail-rank: that rank's C5 workload raises at its first timed step -- the collective sequence must survive it)"""
 import json
 import os
 import sys
@@ -54,6 +55,7 @@ class OracleWorkload:
 
 def main():
     rank, world, port, out, n = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
+    fail_rank = int(sys.argv[6]) if len(sys.argv) > 6 else -1
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import bench
     from jpeg_amd import dist as jd
@@ -71,6 +73,15 @@ def main():
             lo, hi = jd.shard(n, rank, world)
             assert n_images == hi - lo
             made[name] = OracleWorkload(name, n_images, quanta, seed, lo)
+            if rank == fail_rank:   # the set-up step succeeds, the first step inside the timed region raises
+                wl, calls = made[name], [0]
+                real = wl.step
+                def failing_step():
+                    calls[0] += 1
+                    if calls[0] > 1:
+                        raise MemoryError("injected: out of memory on this shard")
+                    real()
+                wl.step = failing_step
         return made[name]
 
     result = bench.run(args, make_workload=make, backend="gloo", device_kind="cpu")

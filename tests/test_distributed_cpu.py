@@ -99,6 +99,31 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert merged == {str(i): W.decode(images[i % W.N_IMAGES], tables) for i in range(n)}
 
 
+def test_bench_two_ranks_one_failing_c5_shard_keeps_the_collectives_paired(tmp_path):
+    """a rank whose C5 shard throws inside the timed region must still meet both barriers, max_over_ranks and
+    all_gather_object -- the job then carries an "error" record (and no throughput) instead of hanging or pairing its
+    collectives with the wrong ones of the healthy rank; the headline (C3) is untouched."""
+    world, n = 2, 5
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    outs = [str(tmp_path / f"bench{r}.json") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_bench_worker.py"), str(r), str(world), str(port), outs[r], str(n), "1"],
+                              stdout=subprocess.PIPE, text=True) for r in range(world)]
+    lines = []
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0
+        lines += [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["parity_vs_oracle"] is True and line["value"] > 0
+    job = line["extra"]["c5_%dx1080p" % n]
+    assert "Mpixels_per_s" not in job and job["error"][0] is None and "injected" in job["error"][1]
+    assert [r["rank"] for r in job["per_rank"]] == [0, 1] and "error" not in job["per_rank"][0]
+    assert job["per_rank"][0]["parity_vs_oracle"] is True
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("size,factors", [((200, 333), [(2, 2), (1, 1), (1, 1)]), ((96, 64), [(2, 1), (1, 1), (1, 1)]),
                                            ((50, 90), [(1, 1), (1, 1), (1, 1)])])

@@ -113,6 +113,22 @@ inline int resident_workgroups_of(int fallback_per_cu)
     return cache[dev].value;
 }
 
+// A raw buffer resource (V#) for `bytes` bytes at `p`, built from wave-uniform values: base[47:0], stride 0, num_records = bytes,
+// word 3 = 0x00020000 (gfx950: 32-bit data format, no swizzle).  buffer_load / buffer_store address base + soffset + voffset
+// (+ the instruction's 12-bit offset) and range-check voffset (+ offset) against num_records - soffset: out-of-range loads
+// return 0, out-of-range stores are dropped (tools/probe_buffer.hip, profiles/r05_probe_buffer.txt).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t make_srd(const void *p, uint32_t bytes)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    i32x4_t r;
+    r.x = (int)(uint32_t)a;
+    r.y = (int)((uint32_t)(a >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
 // LDS byte address of a __shared__ object (low 32 bits of its flat address), wave-uniform
 template <typename T>
 __device__ __forceinline__ uint32_t lds_address(T *p)

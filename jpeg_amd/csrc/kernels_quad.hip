@@ -527,42 +527,44 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
         if constexpr (BX == 32) { sg0 = lane >= 48 ? 1 : 0; sg1 = 1; }
         else { sg0 = (int)((unsigned)lane / CPS); sg1 = (int)((64u + (unsigned)lane) / CPS); }
         const int j0 = lane - CPS * sg0, j1 = 64 + lane - CPS * sg1;
-        const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = sg1 * 8u * pitch + 16u * j1;
-        const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
-        stores_behind_dma = (FAST && full) ? 16 : 0;
+        // FAST: the strip's rows through a BUFFER RESOURCE (round 5).  base = the strip's first pixel, num_records = the bytes from
+        // there to the end of the strip's last row INSIDE the image: a row below the image is out of range and the hardware drops
+        // its store (range check: voffset >= num_records - soffset, tools/probe_buffer.hip); a chunk right of the image gets a
+        // voffset that is out of range for every row.  No predicate, no branch and no 64-bit address per row: the row is the
+        // scalar soffset.  (num_records <= 32 rows x 3 x 65 535 B: the resource describes a strip, not the image, which may
+        // exceed 4 GiB.)
+        const int rows_here = min(8 * BY, a.H - 8 * BY * syi);
+        const i32x4_t out_srd = make_srd(strip_out, (uint32_t)rows_here * pitch);
+        const uint32_t voff0 = (!FAST || col0) ? sg0 * 8u * pitch + 16u * j0 : 0x80000000u;
+        const uint32_t voff1 = (!FAST || col1) ? sg1 * 8u * pitch + 16u * j1 : 0x80000000u;
+        stores_behind_dma = FAST ? 16 : 0;
         JA_PHASE(7)
 
         // One pixel row of the strip's BY block rows at a time, software-pipelined: row y is staged (ds_write) and read
         // back as 16-byte chunks (ds_read) right after its arithmetic, but the chunks are stored only after the arithmetic
         // of the next row; the chroma dwords of the next patch row are requested two rows ahead.
         uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = make_uint4(0, 0, 0, 0);   // chunks of the previous pixel row
-        auto put = [&](uint8_t *o, const uint4 &v, int j) {
-            if constexpr (FAST) {
-                store_nt16(o, v);   // streaming output, never re-read
-            } else {
-                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-                for (int k = 0; k < 16; ++k)
-                    if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
-            }
+        auto put = [&](uint8_t *o, const uint4 &v, int j) {   // FAST = false: byte-wise, the last chunk of a row may be partial
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 16; ++k)
+                if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
         };
         auto store_row = [&](int yy) {
-            uint8_t *rowp = strip_out + (size_t)yy * pitch;   // scalar
 #ifdef JA_X_NOSTORE  // experiment: everything but the global stores
             if (a.W < 0)
 #endif
-            if (FAST && full) {
-                // chunk `lane` from every lane, chunk 64 + lane from lanes 0 .. 31: scalar row base + 32-bit lane offset, and
-                // the second store under a narrowed EXEC instead of a branch.  PRECONDITION: all 64 lanes active -- `FAST && full`
-                // is wave-uniform and this lambda is only called from the unconditional pixel-row loop, so EXEC is -1 here and
-                // is set back to -1, not to a saved copy (a save / restore pair would cost 16 scalar slots per strip)
+            if constexpr (FAST) {
+                // chunk `lane` from every lane, chunk 64 + lane from lanes 0 .. 31 (the others carry an out-of-range voffset):
+                // exactly two store instructions per pixel row, whatever the strip's place in the image
                 const u32x4_t q0 = {pv0.x, pv0.y, pv0.z, pv0.w}, q1 = {pv1.x, pv1.y, pv1.z, pv1.w};
-                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\t"
-                             "s_mov_b64 exec, %5\n\t"
-                             "global_store_dwordx4 %3, %4, %2 nt\n\t"
-                             "s_mov_b64 exec, -1"
-                             ::"v"(voff0), "v"(q0), "s"(rowp), "v"(voff1), "v"(q1), "s"(0xffffffffull) : "memory");
+                const uint32_t soff = (uint32_t)yy * pitch;   // scalar
+                asm volatile("buffer_store_dwordx4 %0, %1, %4, %5 offen nt\n\t"
+                             "buffer_store_dwordx4 %2, %3, %4, %5 offen nt\n\t"
+                             "s_nop 0"   // a store of more than 64 bits with an SGPR offset: one wait state before its data registers may be rewritten
+                             ::"v"(q0), "v"(voff0), "v"(q1), "v"(voff1), "s"(out_srd), "s"(soff) : "memory");
             } else {
+                uint8_t *rowp = strip_out + (size_t)yy * pitch;   // scalar
                 if (col0 && 8 * BY * syi + 8 * sg0 + yy < a.H) put(rowp + voff0, pv0, j0);
                 if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);
             }

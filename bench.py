@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--traffic", default="live", choices=["live", "file", "none"],
                     help="roofline.traffic: measured now under rocprofv3 (c3, N = 1), profiles/traffic_latest.json, or null")
+    ap.add_argument("--valu", default="live", choices=["live", "none"],
+                    help="roofline.valu / extra.c4_encode_4096.valu: the VALU issue roofline of k_quad420 and k_encode_fused, measured now "
+                         "under rocprofv3 (N = 1), or omitted")
     return ap.parse_args()
 
 
@@ -294,6 +297,23 @@ def measure_traffic_live(timeout=240):
     nbytes = int(round((2.0 * out["FETCH_SIZE"][0] + out["WRITE_SIZE"][0]) * 1024))
     return nbytes, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/run_c3.py, "
                     f"mean of {out['FETCH_SIZE'][1]} / {out['WRITE_SIZE'][1]} k_quad420 launches; bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB")
+
+
+def measure_valu_live(which):
+    """The binding roofline (tools/valu_roofline.py): SQ instruction-class counters of the C3 / C4 kernel, measured NOW by two
+    rocprofv3 child runs of the same call on the same workload, turned into VALU issue cycles needed per SIMD / cycles elapsed."""
+    try:
+        from tools import valu_roofline as vr
+        if os.environ.get("JPEG_AMD_LIBRARY"):
+            return {"error": "JPEG_AMD_LIBRARY is set: the timed library is not the product build"}
+        lib = os.path.join(ROOT, "jpeg_amd", "libjpeg_amd.so")
+        if which == "c3":
+            return vr.measure([sys.executable, os.path.join(ROOT, "tools", "run_c3.py"), "24"], "k_quad420<1, 32, true, false>", lib,
+                              "k_quad420ILi1ELi32ELb1ELb0")
+        return vr.measure([sys.executable, os.path.join(ROOT, "tools", "bench_encode.py"), "--only", "4:2:0", "--reps", "24"],
+                          "k_encode_fused<2, 2, true, true, true, 8, false>", lib, "k_encode_fusedILi2ELi2ELb1ELb1ELb1ELi8ELb0")
+    except Exception as e:   # never let the measurement break the headline line
+        return {"error": repr(e)[:300]}
 
 
 def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
@@ -537,6 +557,36 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
                 result["parity_vs_oracle"] = bool(result["parity_vs_oracle"] and parity.get("decode_equals_cpu"))
             if "encode_equals_cpu" in parity and "extra" in result:
                 result["extra"]["c4_encode_4096"]["coefficients_equal_oracle"] = parity["encode_equals_cpu"]
+        # ---- the BINDING roofline: both hot kernels are held by VALU issue (every float operation of the reference is its own
+        #      instruction: no FMA contraction), so the HBM fraction alone does not say how close they are to what the chip can do
+        if world == 1 and getattr(args, "valu", "live") == "live" and workload == "c3":
+            rf = result["roofline"]
+            rf["valu"] = measure_valu_live("c3")
+            if "valu_frac" in rf["valu"]:
+                rf["valu_frac"] = rf["valu"]["valu_frac"]
+                rf["binding"] = ("valu" if rf["valu_frac"] > rf["frac"] else "hbm")
+                rf["binding_note"] = ("k_quad420: fraction of the VALU issue bound (valu_frac) against fraction of the HBM bound (frac): the larger one "
+                                      "binds; neither is at 1 because the two overlap imperfectly (DESIGN.md 6.1)")
+            if "extra" in result and "c4_encode_4096" in result["extra"]:
+                c4 = result["extra"]["c4_encode_4096"]
+                c4["valu"] = measure_valu_live("c4")
+                if "valu_frac" in c4["valu"]:
+                    c4["valu_frac"] = c4["valu"]["valu_frac"]
+                    c4["binding"] = "valu" if c4["valu_frac"] > c4["frac_hbm"] else "hbm"
+        # C5's measured traffic (tools/profile_round.sh -> profiles/traffic_latest.json), reported while it belongs to these kernels
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            key = "c5_%dx1080p" % args.c5_images
+            if "c5" in tj and "extra" in result and key in result["extra"] and args.c5_images == tj["c5"].get("images"):
+                fresh = tj.get("kernel_source_sha16") == kernel_source_sha16()
+                result["extra"][key]["traffic"] = tj["c5"]["hbm_bytes_per_step"] if fresh else None
+                result["extra"][key]["traffic_source"] = (f"rocprofv3 PMC passes of the 4096-image job at commit {tj.get('commit')} (tools/profile_round.sh)"
+                                                          + ("" if fresh else "; STALE: measured with other kernel sources"))
+                if fresh and result["extra"][key].get("GB_per_s"):
+                    alg = result["extra"][key]["GB_per_s"] * result["extra"][key]["ms"] * 1e6
+                    result["extra"][key]["traffic_over_algorithmic"] = round(tj["c5"]["hbm_bytes_per_step"] / alg, 4)
+        except Exception:
+            pass
     if rank == 0:
         print(json.dumps(result), flush=True)
     barrier()

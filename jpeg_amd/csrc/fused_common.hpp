@@ -27,6 +27,22 @@ struct FastDiv {
     }
 };
 
+// A raw buffer resource (V#) for `bytes` bytes at `p`, built from wave-uniform values: base[47:0], stride 0, num_records = bytes,
+// word 3 = 0x00020000 (gfx950: 32-bit data format, no swizzle).  buffer_load / buffer_store address base + soffset + voffset
+// (+ the instruction's 12-bit offset) and range-check voffset (+ offset) against num_records - soffset: out-of-range loads
+// return 0, out-of-range stores are dropped (tools/probe_buffer.hip, profiles/r05_probe_buffer.txt).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t make_srd(const void *p, uint32_t bytes)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    i32x4_t r;
+    r.x = (int)(uint32_t)a;
+    r.y = (int)((uint32_t)(a >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+
 // One 16-byte-per-lane LDS-DMA: lane l's 16 B at `g` land at LDS byte address lds + 16 l.
 // Issued from inline asm on purpose: hipcc cannot tell which LDS array a DMA targets, so
 // after a __builtin_amdgcn_global_load_lds it makes the NEXT LDS read of any array wait with
@@ -83,6 +99,34 @@ __device__ __forceinline__ void lds_dma16_run(uint64_t sbase, uint32_t v0, uint3
                          ::"s"(sbase), "v"(v0), "v"(v1), "s"(lds) : "memory");
     }
 }
+// The same run through a buffer resource: source = srd.base + soff + per-lane offset (+ 1 KiB per piece), hardware range check
+// against srd.num_records -- a lane whose 16 bytes lie outside the resource transfers ZEROS (tools/probe_buffer.hip T2), so
+// block rows above / below a plane and runs that overhang its end need no clamped addresses.  `soff` must be a true,
+// non-negative byte offset (or one that is out of range as an unsigned number).  s_nop 3: M0 is read one wait state after its
+// write, and an SGPR operand the compiler happened to produce with v_readfirstlane five.
+template <int N, bool NT>
+__device__ __forceinline__ void lds_dma16_brun(i32x4_t srd, uint32_t soff, uint32_t v0, uint32_t v1, uint32_t lds)
+{
+    static_assert(N == 1 || N == 2 || N == 4, "runs of 1, 2 or 4 KiB");
+#define JA_BL(v, off, hint) "buffer_load_dwordx4 " v ", %0, %1 offen" off hint " lds"
+    if constexpr (N == 1) {
+        if constexpr (NT) asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\t" JA_BL("%2", "", " nt") ::"s"(srd), "s"(soff), "v"(v0), "v"(v1), "s"(lds) : "memory");
+        else asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\t" JA_BL("%2", "", JA_KEEP_HINT) ::"s"(srd), "s"(soff), "v"(v0), "v"(v1), "s"(lds) : "memory");
+    } else if constexpr (N == 2) {
+        if constexpr (NT) asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\t" JA_BL("%2", "", " nt") "\n\t" JA_BL("%3", " offset:1024", " nt")
+                                       ::"s"(srd), "s"(soff), "v"(v0), "v"(v1), "s"(lds) : "memory");
+        else asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\t" JA_BL("%2", "", JA_KEEP_HINT) "\n\t" JA_BL("%3", " offset:1024", JA_KEEP_HINT)
+                          ::"s"(srd), "s"(soff), "v"(v0), "v"(v1), "s"(lds) : "memory");
+    } else {
+        if constexpr (NT) asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\t" JA_BL("%2", "", " nt") "\n\t" JA_BL("%3", " offset:1024", " nt") "\n\t"
+                                       JA_BL("%2", " offset:2048", " nt") "\n\t" JA_BL("%3", " offset:3072", " nt")
+                                       ::"s"(srd), "s"(soff), "v"(v0), "v"(v1), "s"(lds) : "memory");
+        else asm volatile("s_mov_b32 m0, %4\n\ts_nop 3\n\t" JA_BL("%2", "", JA_KEEP_HINT) "\n\t" JA_BL("%3", " offset:1024", JA_KEEP_HINT) "\n\t"
+                          JA_BL("%2", " offset:2048", JA_KEEP_HINT) "\n\t" JA_BL("%3", " offset:3072", JA_KEEP_HINT)
+                          ::"s"(srd), "s"(soff), "v"(v0), "v"(v1), "s"(lds) : "memory");
+    }
+#undef JA_BL
+}
 // 4 bytes per lane: lane l's dword lands at LDS byte address lds + 4 l.
 __device__ __forceinline__ void lds_dma4_s(uint64_t sbase, uint32_t voff, uint32_t lds)
 {
@@ -111,22 +155,6 @@ inline int resident_workgroups_of(int fallback_per_cu)
     if (dev >= kMaxDevices) return query();
     std::call_once(cache[dev].once, [&]() { cache[dev].value = query(); });
     return cache[dev].value;
-}
-
-// A raw buffer resource (V#) for `bytes` bytes at `p`, built from wave-uniform values: base[47:0], stride 0, num_records = bytes,
-// word 3 = 0x00020000 (gfx950: 32-bit data format, no swizzle).  buffer_load / buffer_store address base + soffset + voffset
-// (+ the instruction's 12-bit offset) and range-check voffset (+ offset) against num_records - soffset: out-of-range loads
-// return 0, out-of-range stores are dropped (tools/probe_buffer.hip, profiles/r05_probe_buffer.txt).
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ i32x4_t make_srd(const void *p, uint32_t bytes)
-{
-    const uint64_t a = reinterpret_cast<uint64_t>(p);
-    i32x4_t r;
-    r.x = (int)(uint32_t)a;
-    r.y = (int)((uint32_t)(a >> 32) & 0xffffu);
-    r.z = (int)bytes;
-    r.w = 0x00020000;
-    return r;
 }
 
 // LDS byte address of a __shared__ object (low 32 bits of its flat address), wave-uniform

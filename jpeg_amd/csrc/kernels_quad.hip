@@ -77,7 +77,7 @@ template <int BX> struct QuadShape {
 };
 
 // MODE: 0 = YCbCr bytes, 1 = RGB bytes.  FAST: W % 16 == 0 and 16-byte aligned rows, so every 16-byte chunk of a row
-// segment is entirely inside the image or entirely outside (no byte-wise tail code).
+// segment is entirely inside the image or entirely outside (no tail code for the partial last chunk of a row).
 template <int MODE, int BX, bool FAST, bool DYN>
 __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
 {
@@ -144,100 +144,77 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
     const int strips_y = (a.uy + BY - 1) / BY;
     auto role_of = [&](int t) -> int { return (qp + 2 * (t & 1)) & 3; };
 
-    // LDS-DMA of a pass's blocks: instruction i moves 64 x 16 B; slot u = 64 i + lane holds chunk (u & 7) ^ ((b >> 1) & 7)
-    // of block b = u >> 3 -- the XOR on the SOURCE address makes the later per-work-item ds_read_b128 (stride 128 B)
-    // bank-conflict-free.  Where the eight blocks of an instruction are neighbours in a block row, the block index is
-    // scalar and only the lane's place inside the group is per lane (`ve`; odd i: chunk ^ 4).
-    auto dma_chroma_one = [&](int i, int img, int syi, int sxi, int lane, int role) {
+    // LDS-DMA of a pass's blocks: an instruction moves 64 x 16 B; slot u = 64 i + lane of the wave's buffer holds chunk
+    // (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3 -- the XOR on the SOURCE address makes the later per-work-item ds_read_b128
+    // (stride 128 B) bank-conflict-free.  The eight blocks of an instruction are neighbours in a block row: the block index is
+    // scalar and only the lane's place inside the group is per lane (`ve`; odd pieces: chunk ^ 4).
+    // Round 5: the runs go through BUFFER RESOURCES.  Luma: a resource over the strip's block rows inside the plane (base
+    // advanced to the strip's first row in 64 bits -- a luma plane may exceed 4 GiB -- num_records = those rows); chroma: one
+    // over the whole plane (at most 4096 x 4096 blocks = 2 GiB).  The run's place is one scalar byte offset.  Block rows above /
+    // below the plane and runs that overhang the end of the resource are out of range and arrive as zeros; runs that overhang
+    // the end of a block ROW fetch the head of the next row.  Either way those blocks are "fetched, not used": their pixels are
+    // dropped by the store's range check, their chroma samples repaired in the tile (copy_row, fix_columns).  No clamped
+    // addresses, no interior / edge split, no 64-bit address per run.
+    auto lane_chunk = [&](int lane) -> uint32_t {
         const uint32_t l3 = lane >> 3;
-        const int b = 8 * i + (int)l3;
-        const int top = syi - qp;                             // strip row of the stack's first strip
-        int pl, bx, row;
-        if (role < 3) {   // runs of eight neighbouring blocks
-            int col0;
-            if (role < 2) {
-                if constexpr (BX == 32) { pl = (i >> 1) & 1; row = top + 2 * role + (i >> 2); col0 = 8 * (i & 1); }
-                else { pl = (i >> 1) & 1; row = CBR * (top + 2 * role + (i >> 2)) + (i & 1); col0 = 0; }
-            } else {
-                if (8 * i >= NHROW) return;
-                const int below = (8 * i) / (2 * CBW);
-                pl = ((8 * i) / CBW) & 1; col0 = (8 * i) % CBW;
-                row = below ? CBR * (top + QS) : CBR * top - 1;
-            }
-            row = min(max(row, 0), a.uyc - 1);   // missing rows: fetched, not used
-            if (CBW * sxi + CBW <= a.uxc) {   // wave-uniform: the strip's chroma columns lie inside the plane
-                const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
-                const uint64_t sb = reinterpret_cast<uint64_t>(a.coef[1 + pl] + img * a.coef_stride[1 + pl]) +
-                                    ((uint64_t)((uint32_t)row * (uint32_t)a.uxc + (uint32_t)(CBW * sxi + col0)) << 7);
-                lds_dma16_s_keep(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
-                return;
-            }
-            bx = CBW * sxi + col0 + (int)l3;
-        } else {
-            if (8 * i >= NSIDE) return;
-            pl = (b >> 1) & 1; row = min(max(CBR * top - 1 + (b >> 2), 0), a.uyc - 1);
-            bx = (b & 1) ? CBW * sxi + CBW : CBW * sxi - 1;
-        }
-        const int16_t *cbase = a.coef[1 + pl] + img * a.coef_stride[1 + pl];
-        const uint32_t blk = (bx >= 0 && bx < a.uxc) ? (uint32_t)row * a.uxc + bx : 0u;   // outside the plane: fetched, not used
-        const int c = (lane & 7) ^ ((b >> 1) & 7);
-        lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+        return l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
     };
-    auto dma_luma_one = [&](int i, int img, int syi, int sxi, int lane) {
-        const int16_t *base = a.coef[0] + img * a.coef_stride[0];
-        const uint32_t l3 = lane >> 3;
-        if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {   // interior strip (wave-uniform)
-            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
-            const uint32_t blk0 = (uint32_t)(BY * syi + i / (BX / 8)) * a.ux + sxi * BX + 8 * (i % (BX / 8));
-            const uint64_t sb = reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7);
-            lds_dma16_s(sb, (i & 1) ? ve ^ 64u : ve, coef_lds + 1024 * i);
-            return;
-        }
-        const int b = 8 * i + (int)l3;  // block within the strip: column b % BX, row b / BX
-        const int bx = sxi * BX + (b & (BX - 1)), by = BY * syi + (int)((unsigned)b / BX);
-        // blocks outside the plane fetch block 0; the store predicate discards their pixels
-        const uint32_t blk = (bx < a.ux && by < a.uy) ? (uint32_t)by * a.ux + bx : 0u;
-        const int c = (lane & 7) ^ ((b >> 1) & 7);
-        lds_dma16(reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
-    };
-
-    // a whole pass at once.  Interior strips / stacks whose blocks lie in runs of 2 or 4 KiB take one M0 write and one scalar
-    // base per run (lds_dma16_run); everything else goes piece by piece.
-    auto dma_luma = [&](int img, int syi, int sxi, int lane) {
-        if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {   // interior strip (wave-uniform): BY runs of BX blocks
-            const uint32_t l3 = lane >> 3;
-            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
-            const uint64_t base = reinterpret_cast<uint64_t>(a.coef[0] + img * a.coef_stride[0]);
+    // (sgpr(): the value re-defined in a scalar register.  Everything that ends in an "s" operand of the DMA statements is
+    // computed from such copies: left alone, LLVM may keep a kernel argument that vector code also reads in a VGPR, select the
+    // multiplications by it as VALU instructions and then have no scalar register to offer the statement)
+    auto sgpr = [](uint32_t v) -> uint32_t { asm volatile("" : "+s"(v)); return v; };
+    auto dma_luma = [&](int img, int syi, int sxi, int lane) {   // BY runs of BX blocks (the strip is not phantom)
+        const uint32_t ve = lane_chunk(lane);
+        const uint32_t ux = sgpr((uint32_t)a.ux);
+        const uint32_t row0 = (uint32_t)(BY * syi), rows = (uint32_t)min(BY, a.uy - BY * syi);
+        const char *base = reinterpret_cast<const char *>(a.coef[0] + img * a.coef_stride[0]) + ((uint64_t)(row0 * ux) << 7);
+        const i32x4_t srd = make_srd(base, (rows * ux) << 7);
 #pragma unroll
-            for (int r = 0; r < BY; ++r) {
-                const uint32_t blk0 = (uint32_t)(BY * syi + r) * a.ux + sxi * BX;
-                lds_dma16_run<BX / 8, true>(base + ((uint64_t)blk0 << 7), ve, ve ^ 64u, coef_lds + r * (BX * 128));
-            }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dma_luma_one(i, img, syi, sxi, lane);
+        for (int r = 0; r < BY; ++r)
+            lds_dma16_brun<BX / 8, true>(srd, ((uint32_t)r * ux + (uint32_t)(sxi * BX)) << 7, ve, ve ^ 64u, coef_lds + r * (BX * 128));
     };
+    // byte offset of block (row, col) of a chroma plane; a row above the plane (-1) wraps to an offset near 2^32 and a row
+    // below it lies at or behind num_records (<= 2^31): both out of range
     auto dma_chroma = [&](int img, int syi, int sxi, int lane, int role) {
-        if constexpr (BX == 32) {
-            if (role < 3 && CBW * sxi + CBW <= a.uxc) {   // wave-uniform: four runs of sixteen neighbouring blocks
-                const uint32_t l3 = lane >> 3;
-                const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
-                const int top = syi - qp;
+        const int top = syi - qp;                             // strip row of the stack's first strip
+        const uint32_t uxc = sgpr((uint32_t)a.uxc);
+        const uint32_t plane_bytes = sgpr(((uint32_t)a.uyc * uxc) << 7);
+        auto chroma_off = [&](int row, int col) -> uint32_t { return ((uint32_t)row * uxc + (uint32_t)col) << 7; };
+        if (role < 3) {   // runs of neighbouring blocks, one plane each
+            const uint32_t ve = lane_chunk(lane);
+            const char *base_b = reinterpret_cast<const char *>(a.coef[1] + img * a.coef_stride[1]);
+            const char *base_r = reinterpret_cast<const char *>(a.coef[2] + img * a.coef_stride[2]);
+            if constexpr (BX == 32) {   // four runs of sixteen blocks
+                const i32x4_t srd_b = make_srd(base_b, plane_bytes), srd_r = make_srd(base_r, plane_bytes);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {   // pieces 2 u, 2 u + 1 of dma_chroma_one
-                    const int pl = u & 1;
-                    int row = role < 2 ? top + 2 * role + (u >> 1) : ((u >> 1) ? CBR * (top + QS) : CBR * top - 1);
-                    row = min(max(row, 0), a.uyc - 1);   // missing rows: fetched, not used
-                    const uint64_t sb = reinterpret_cast<uint64_t>(a.coef[1 + pl] + img * a.coef_stride[1 + pl]) +
-                                        ((uint64_t)((uint32_t)row * (uint32_t)a.uxc + (uint32_t)(CBW * sxi)) << 7);
-                    lds_dma16_run<2, false>(sb, ve, ve ^ 64u, coef_lds + 2048 * u);
+                for (int u = 0; u < 4; ++u) {
+                    const int row = role < 2 ? top + 2 * role + (u >> 1) : ((u >> 1) ? CBR * (top + QS) : CBR * top - 1);
+                    lds_dma16_brun<2, false>((u & 1) ? srd_r : srd_b, chroma_off(row, CBW * sxi), ve, ve ^ 64u, coef_lds + 2048 * u);
                 }
-                return;
-            }
-        }
+            } else {                    // pieces of eight blocks: role 0, 1 eight of them (a block row each), role 2 four
 #pragma unroll
-        for (int i = 0; i < NDMA_C; ++i) dma_chroma_one(i, img, syi, sxi, lane, role);
+                for (int i = 0; i < NDMA_C; ++i) {
+                    if (role == 2 && 8 * i >= NHROW) break;
+                    const int pl = role < 2 ? (i >> 1) & 1 : i & 1;   // (scalar)
+                    const int row = role < 2 ? CBR * (top + 2 * role + (i >> 2)) + (i & 1) : ((i >> 1) ? CBR * (top + QS) : CBR * top - 1);
+                    lds_dma16_brun<1, false>(make_srd(pl ? base_r : base_b, plane_bytes), chroma_off(row, CBW * sxi), (i & 1) ? ve ^ 64u : ve, 0u, coef_lds + 1024 * i);
+                }
+            }
+            return;
+        }
+        // role 3: the neighbour blocks left and right of the stack, block by block (two planes within one instruction:
+        // per-lane addresses; a block outside the plane fetches block 0 and is not used)
+#pragma unroll
+        for (int i = 0; i < NDMA_C; ++i) {
+            if (8 * i >= NSIDE) break;
+            const int b = 8 * i + (lane >> 3);
+            const int pl = (b >> 1) & 1, row = min(max(CBR * top - 1 + (b >> 2), 0), a.uyc - 1);
+            const int bx = (b & 1) ? CBW * sxi + CBW : CBW * sxi - 1;
+            const int16_t *cbase = a.coef[1 + pl] + img * a.coef_stride[1 + pl];
+            const uint32_t blk = (bx >= 0 && bx < a.uxc) ? (uint32_t)row * a.uxc + bx : 0u;
+            const int c = (lane & 7) ^ ((b >> 1) & 7);
+            lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+        }
     };
 
 #ifdef JA_X_STAGGER   // experiment: the three workgroups of a CU start a third of a strip apart
@@ -535,9 +512,15 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
         // scalar soffset.  (num_records <= 32 rows x 3 x 65 535 B: the resource describes a strip, not the image, which may
         // exceed 4 GiB.)
         const int rows_here = min(8 * BY, a.H - 8 * BY * syi);
-        const i32x4_t out_srd = make_srd(strip_out, (uint32_t)rows_here * pitch);
-        const uint32_t voff0 = (!FAST || col0) ? sg0 * 8u * pitch + 16u * j0 : 0x80000000u;
-        const uint32_t voff1 = (!FAST || col1) ? sg1 * 8u * pitch + 16u * j1 : 0x80000000u;
+        const uint32_t strip_bytes = (uint32_t)rows_here * pitch;
+        const i32x4_t out_srd = make_srd(strip_out, strip_bytes);
+        // FAST: every chunk is whole or outside.  Otherwise (any width: rows start at any byte address, which buffer stores
+        // take) a chunk is whole, outside, or -- in the strip column that holds the image's right edge -- the PARTIAL last chunk
+        // of its row segment (1 .. 15 bytes), which goes dword- and byte-wise (store_tail below).
+        const int rem0 = col0 ? nb - 16 * j0 : 0, rem1 = col1 ? nb - 16 * j1 : 0;   // bytes of the lane's chunks inside the image
+        const uint32_t base0 = sg0 * 8u * pitch + 16u * j0, base1 = sg1 * 8u * pitch + 16u * j1;
+        const uint32_t voff0 = (FAST ? col0 : rem0 >= 16) ? base0 : 0x80000000u;
+        const uint32_t voff1 = (FAST ? col1 : rem1 >= 16) ? base1 : 0x80000000u;
         stores_behind_dma = FAST ? 16 : 0;
         JA_PHASE(7)
 
@@ -545,16 +528,26 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
         // back as 16-byte chunks (ds_read) right after its arithmetic, but the chunks are stored only after the arithmetic
         // of the next row; the chroma dwords of the next patch row are requested two rows ahead.
         uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = make_uint4(0, 0, 0, 0);   // chunks of the previous pixel row
-        auto put = [&](uint8_t *o, const uint4 &v, int j) {   // FAST = false: byte-wise, the last chunk of a row may be partial
-            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-            for (int k = 0; k < 16; ++k)
-                if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
+        // FAST = false, right-edge column: the first `rem` (1 .. 15) bytes of a chunk -- up to three dwords, then up to three
+        // bytes; a lane without a partial chunk carries out-of-range offsets throughout (rem outside 1 .. 15)
+        auto store_tail = [&](const uint4 &v, uint32_t base, int rem, uint32_t soff) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(strip_out, 0, (int)strip_bytes, 0x00020000);
+            const bool part = rem > 0 && rem < 16;
+            const int nd = rem >> 2, nbytes = rem & 3;
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                __builtin_amdgcn_raw_buffer_store_b32(d[k], rsrc, (part && k < nd) ? base + 4u * k : 0x80000000u, soff, 0);
+            const uint32_t w = nd == 0 ? v.x : nd == 1 ? v.y : nd == 2 ? v.z : v.w;
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(w >> (8 * b)), rsrc, (part && b < nbytes) ? base + 4u * nd + b : 0x80000000u, soff, 0);
         };
         auto store_row = [&](int yy) {
 #ifdef JA_X_NOSTORE  // experiment: everything but the global stores
             if (a.W < 0)
 #endif
-            if constexpr (FAST) {
+            {
                 // chunk `lane` from every lane, chunk 64 + lane from lanes 0 .. 31 (the others carry an out-of-range voffset):
                 // exactly two store instructions per pixel row, whatever the strip's place in the image
                 const u32x4_t q0 = {pv0.x, pv0.y, pv0.z, pv0.w}, q1 = {pv1.x, pv1.y, pv1.z, pv1.w};
@@ -563,10 +556,12 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
                              "buffer_store_dwordx4 %2, %3, %4, %5 offen nt\n\t"
                              "s_nop 0"   // a store of more than 64 bits with an SGPR offset: one wait state before its data registers may be rewritten
                              ::"v"(q0), "v"(voff0), "v"(q1), "v"(voff1), "s"(out_srd), "s"(soff) : "memory");
-            } else {
-                uint8_t *rowp = strip_out + (size_t)yy * pitch;   // scalar
-                if (col0 && 8 * BY * syi + 8 * sg0 + yy < a.H) put(rowp + voff0, pv0, j0);
-                if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);
+                if constexpr (!FAST) {
+                    if (nb & 15) {   // wave-uniform: this strip column holds the image's right edge
+                        store_tail(pv0, base0, rem0, soff);
+                        store_tail(pv1, base1, rem1, soff);
+                    }
+                }
             }
         };
 #pragma unroll

@@ -138,6 +138,22 @@ int jpeg_amd_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
                     const int16_t *const d_coef[], const uint16_t *h_quanta, int ntables,
                     int cosited, jpeg_amd_color color, uint8_t *d_pixels);
 
+/* Fused Spectral -> Rectangular: == idct().interleaved(cosite:) bit for bit (decode.swift:4154-4165, 4182-4276) -- what
+ * Rectangular.decompress(stream:cosite:) runs behind the entropy decoder (decode.swift:4367-4374) -- for ANY JPEG.Format
+ * (jpeg.swift:21-56; examples/custom-color/main.swift:41-63): precision 1 .. 16, 1 .. 4 planes, centred or cosited.
+ * Layouts whose planes lie at the image's scale or at half of it per axis (factors 1 | 2, scale <= 2) take ONE launch with no
+ * Planar intermediate in HBM (kernels_generic.hip; the reference's literal operation sequence: true division, .rounded());
+ * every other layout (factors 3, 4 ...) runs the staged kernels through the context's scratch -- same result either way.
+ * d_rect: uint16 [H][W][nplanes]; batch strides as in jpeg_amd_decode_batch (rect_stride in uint16 elements). */
+int jpeg_amd_spectral_rectangular_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout, int n_images,
+                                        const int16_t *const d_coef[], const size_t coef_stride[],
+                                        const uint16_t *d_quanta, size_t quanta_stride, int ntables,
+                                        int cosited, uint16_t *d_rect, size_t rect_stride);
+/* single image, host tables */
+int jpeg_amd_spectral_rectangular(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                                  const int16_t *const d_coef[], const uint16_t *h_quanta, int ntables,
+                                  int cosited, uint16_t *d_rect);
+
 /* ---- encode stages (device-resident) ---------------------------------------------- */
 
 /* Rectangular.pack(size:layout:metadata:pixels:)  encode.swift:453-464 */

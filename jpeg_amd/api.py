@@ -220,6 +220,20 @@ class Spectral:
             _ptrs(out)), "jpeg_amd_spectral_idct", self.ctx.handle)
         return Planar(self.ctx, self.size, self.layout, out)
 
+    def rectangular(self, cosite: bool = False) -> "Rectangular":
+        """Fused idct().interleaved(cosite:) (decode.swift:4154-4165, 4182-4276) -> Rectangular: any format (precision 1 .. 16,
+        1 .. 4 planes); one launch with no Planar in HBM where the planes lie at the image's scale or at half of it, the staged
+        kernels otherwise -- the same samples either way."""
+        torch = _torch()
+        L = self._layout()
+        W, H = self.size
+        out = self.ctx.empty(W * H * self.layout.count, torch.int16)
+        qarr, qptr = _quanta_array(self.quanta)
+        _lib.check(_lib.lib().jpeg_amd_spectral_rectangular(
+            self.ctx.handle, C.byref(L), _ptrs(self.planes), qptr, len(self.quanta), 1 if cosite else 0, out.data_ptr()),
+            "jpeg_amd_spectral_rectangular", self.ctx.handle)
+        return Rectangular(self.ctx, self.size, self.layout, out.view(H, W, self.layout.count))
+
     def decode(self, color=RGB, cosite: bool = False):
         """Fused idct().interleaved(cosite:).unpack(as:) -> uint8 tensor [H*W, 3]."""
         torch = _torch()
@@ -480,7 +494,7 @@ class Rectangular:
     def decompress(cls, ctx: Context, source, cosite: bool = False) -> "Rectangular":
         """Rectangular.decompress(stream:cosite:) -- decode.swift:4367-4374:
         Spectral.decompress(...).idct().interleaved(cosite:)."""
-        return Spectral.decompress(ctx, source).idct().interleaved(cosite=cosite)
+        return Spectral.decompress(ctx, source).rectangular(cosite=cosite)
 
     @classmethod
     def pack(cls, ctx, size, layout, pixels, color=RGB) -> "Rectangular":

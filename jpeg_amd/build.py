@@ -17,14 +17,17 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libjpeg_amd.so")
 
-SOURCES = ["kernels_stage.hip", "kernels_fused.hip", "kernels_quad.hip", "kernels_encode.hip", "capi.hip", "entropy.cpp", "entropy_encode.cpp"]
+SOURCES = ["kernels_stage.hip", "kernels_fused.hip", "kernels_quad.hip", "kernels_encode.hip", "kernels_generic.hip", "capi.hip", "entropy.cpp", "entropy_encode.cpp"]
 HEADERS = ["dct.hpp", "kernels.hpp", "upsample.hpp", "fused_common.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-command-line-argument"]
 
 
-# kernels that must not touch scratch memory: source -> mangled-name fragment
-NO_SCRATCH = {"kernels_quad.hip": "k_quad420", "kernels_fused.hip": "k_luma_fused"}
+# kernels that must not touch scratch memory: source -> mangled-name fragment.  The strip walks count their own VM operations
+# (a compiler-placed spill would break the count); for the encode and generic kernels a spill is a performance bug -- a reload
+# waits with vmcnt(0) for every store in flight -- that has crept in before (round 4: the byte-tail encode variants).
+NO_SCRATCH = {"kernels_quad.hip": "k_quad420", "kernels_fused.hip": "k_luma_fused", "kernels_encode.hip": "k_encode_fused",
+              "kernels_generic.hip": "k_generic_fused"}
 
 
 def check_no_scratch(src: str, remarks: str, fragment: str) -> None:
@@ -42,7 +45,7 @@ def check_no_scratch(src: str, remarks: str, fragment: str) -> None:
     if seen == 0:
         raise RuntimeError(f"{src}: no resource remarks for {fragment} (the spill gate cannot see the kernels)")
     if bad:
-        raise RuntimeError(f"{src}: kernels that count their own VM operations must not spill:\n  " + "\n  ".join(bad))
+        raise RuntimeError(f"{src}: kernels of the spill gate (NO_SCRATCH) must not spill:\n  " + "\n  ".join(bad))
 
 
 def hipcc() -> str:
@@ -63,17 +66,26 @@ def _stale() -> bool:
 
 def sync_swift_header() -> None:
     """swift/Sources/CJPEGAMD/jpeg_amd.h is a generated copy of include/jpeg_amd.h (the module map needs the header inside
-    the C target's directory); tests/test_abi_cpu.py checks that the two are identical."""
+    the C target's directory); tests/test_abi_cpu.py checks that the two are identical.  Only the explicit build
+    (`python -m jpeg_amd.build`) writes it -- never a library load, which may run on a read-only checkout or as several
+    ranks at once -- and it writes atomically."""
     src = os.path.join(INCLUDE, "jpeg_amd.h")
     dst = os.path.join(os.path.dirname(HERE), "swift", "Sources", "CJPEGAMD", "jpeg_amd.h")
-    if os.path.isdir(os.path.dirname(dst)):
-        data = open(src, "rb").read()
-        if not os.path.exists(dst) or open(dst, "rb").read() != data:
-            open(dst, "wb").write(data)
+    if not os.path.isdir(os.path.dirname(dst)):
+        return
+    data = open(src, "rb").read()
+    try:
+        if os.path.exists(dst) and open(dst, "rb").read() == data:
+            return
+        tmp = f"{dst}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, dst)
+    except OSError as e:
+        sys.stderr.write(f"jpeg_amd.build: could not refresh {dst}: {e}\n")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    sync_swift_header()
     if not (force or _stale()):
         return LIB
     cc = hipcc()
@@ -105,4 +117,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
+    sync_swift_header()
     print(build(force="--force" in sys.argv, verbose=True))

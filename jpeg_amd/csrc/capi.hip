@@ -449,6 +449,57 @@ int jpeg_amd_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const int16_t *
                                  d_pixels, 0);
 }
 
+int jpeg_amd_spectral_rectangular_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_images,
+                                        const int16_t *const d_coef[], const size_t coef_stride[],
+                                        const uint16_t *d_quanta, size_t quanta_stride, int ntables,
+                                        int cosited, uint16_t *d_rect, size_t rect_stride)
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    JA_TRY(check_planes_cover_image(L));
+    if (n_images < 0 || n_images > 65535) return JPEG_AMD_EINVAL;
+    if (n_images == 0) return JPEG_AMD_OK;
+    if (!d_coef || !coef_stride || !d_quanta || !d_rect) return JPEG_AMD_EINVAL;
+    for (int p = 0; p < L->nplanes; ++p)
+        if (!d_coef[p]) return JPEG_AMD_EINVAL;
+    PlaneSet cs{};
+    for (int p = 0; p < L->nplanes; ++p) { cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p]; }
+    if (generic_fused_supported(*L)) {
+        JA_HIP(ctx, launch_generic_fused(ctx->stream, n_images, *L, cs, QuantaRef{d_quanta, quanta_stride}, cosited != 0,
+                                         d_rect, rect_stride));
+        return JPEG_AMD_OK;
+    }
+    // staged path (any factors): IDCT every plane into uint16 scratch planes, then upsample + interleave
+    size_t offset[JPEG_AMD_MAX_PLANES], total = 0;
+    for (int p = 0; p < L->nplanes; ++p) {
+        offset[p] = total;
+        total += align256(plane_samples(L, p) * (size_t)n_images * sizeof(uint16_t));
+    }
+    JA_TRY(ensure_scratch(ctx, total));
+    PlaneSet ps{};
+    for (int p = 0; p < L->nplanes; ++p) {
+        uint8_t *dst = static_cast<uint8_t *>(ctx->scratch) + offset[p];
+        JA_HIP(ctx, launch_idct_plane(ctx->stream, n_images, d_coef[p], coef_stride[p], QuantaRef{d_quanta, quanta_stride},
+                                      L->qi[p], L->units_x[p], L->units_y[p], L->precision, dst, plane_samples(L, p), false));
+        ps.ptr[p] = dst;
+        ps.stride[p] = plane_samples(L, p);
+    }
+    JA_HIP(ctx, launch_planar_to_pixels(ctx->stream, n_images, *L, ps, false, cosited != 0, PixelKind::Rect16, d_rect,
+                                        rect_stride * sizeof(uint16_t)));
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_spectral_rectangular(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const int16_t *const d_coef[],
+                                  const uint16_t *h_quanta, int ntables, int cosited, uint16_t *d_rect)
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
+    const size_t zero[JPEG_AMD_MAX_PLANES] = {0, 0, 0, 0};
+    return jpeg_amd_spectral_rectangular_batch(ctx, L, 1, d_coef, zero, d_q, 0, ntables, cosited, d_rect, 0);
+}
+
 // ---- encode stages ----------------------------------------------------------------------
 
 int jpeg_amd_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *d_pixels, size_t npixels,

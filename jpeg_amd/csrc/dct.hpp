@@ -281,6 +281,9 @@ __device__ __forceinline__ float dpp_f32(float v, int ctrl_row_shl4_quad1032_qua
 __device__ __forceinline__ void idct_edge_col_split(const int (&coef)[8], const float (&q)[8], float level, bool first, int j,
                                                     float (&edge)[8])
 {
+#ifdef JA_DEBUG_ASSERTS   // the precondition, checked in debug builds: all 64 lanes active (a DPP read of an inactive lane keeps the old value)
+    if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+#endif
     float h[8], f[8];
 #pragma unroll
     for (int hh = 0; hh < 8; ++hh) h[hh] = q[hh] * (float)coef[hh];

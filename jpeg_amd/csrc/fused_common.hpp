@@ -175,6 +175,9 @@ __device__ __forceinline__ uint32_t lds_address(T *p)
 __device__ __forceinline__ void lds_arrive(uint32_t *counter)
 {
     const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)counter;
+#ifdef JA_DEBUG_ASSERTS   // the precondition, checked in debug builds: lane 0 is active here
+    if (!(__builtin_amdgcn_read_exec() & 1ull)) __builtin_trap();
+#endif
     uint64_t saved;
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(saved) : "v"(addr), "v"(1u) : "memory");
 }

@@ -76,6 +76,12 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
                               const PlaneSet &coef, QuantaRef q, bool rgb, uint32_t *d_walk_counters,
                               uint8_t *d_pixels, size_t pixel_stride);
 
+// Spectral -> Rectangular (uint16 [H][W][count]) in one launch for the JPEG.Format plug-in path (kernels_generic.hip): any
+// precision 1 .. 16, 1 .. 4 planes, centred or cosited, every plane at the image's scale or at half of it per axis.
+bool       generic_fused_supported(const jpeg_amd_layout &layout);
+hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd_layout &layout, const PlaneSet &coef,
+                                QuantaRef q, bool cosited, uint16_t *d_rect, size_t rect_stride);
+
 // ---- encode -------------------------------------------------------------------------
 // a13: Rectangular.pack
 hipError_t launch_pack(hipStream_t stream, const uint8_t *d_pixels, size_t npixels,

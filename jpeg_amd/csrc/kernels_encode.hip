@@ -33,6 +33,8 @@
 #include <cstdlib>
 #include <utility>
 
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
 namespace jpeg_amd {
 
 namespace {
@@ -407,6 +409,8 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
         //      converts all 192 bytes to floats up front. ----
         uint32_t pix[8][6];
         const bool inside = 8 * bx + 8 <= a.W && 8 * by + 8 <= a.H;
+        bool ragged = false;   // the block holds the image's last pixel column, or lies right of it
+        int xlast = 7;
         if (FASTIN && inside) {
             // scalar row base (the tile's first pixel row + y rows: SALU) + one 32-bit per-lane offset for all eight rows:
             // no vector address arithmetic per row (it used to be three 64-bit multiply-adds per row)
@@ -423,20 +427,37 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
                 pix[y][0] = p0.x; pix[y][1] = p0.y; pix[y][2] = p1.x; pix[y][3] = p1.y; pix[y][4] = p2.x; pix[y][5] = p2.y;
             }
         } else {
-            // edge blocks / unaligned images: clamped byte loads, packed into the same layout
+            // Edge blocks, and every block of an image whose rows are not 8-byte aligned (any width): the block's 8 x 24 bytes
+            // through a BUFFER RESOURCE (round 5; it was 192 clamped byte loads per block, and the variant spilled 36-48 VGPRs).
+            // Row y of the block is image row min(8 by + y, H - 1) -- edge replicate downwards, encode.swift:417 -- and its 24
+            // bytes start at pixel min(8 bx, W - 1): dword loads at any byte address (the hardware takes them), bytes past the end
+            // of the image arrive as zeros (range check) and pixels right of column W - 1 are replaced below (`ragged`,
+            // encode.swift:416).  The resource starts at the tile's first row inside the image, so that offsets stay 32-bit
+            // for images beyond 4 GiB (<= 128 rows x 3 x 65 535 B).
+            const int r0 = min(8 * tyi * TY, a.H - 1);
+            const size_t left = (size_t)(a.H - r0) * a.W * 3;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t *>(base) + (size_t)r0 * a.W * 3, 0, (int)(uint32_t)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
+            const int xs = min(8 * bx, a.W - 1);
+            ragged = a.W - 1 - xs < 7;
+            xlast = a.W - 1 - xs;
 #pragma unroll
             for (int y = 0; y < 8; ++y) {
-                __builtin_amdgcn_sched_barrier(0);
-                const uint8_t *row = base + (size_t)min(8 * by + y, a.H - 1) * a.W * 3;
+                const uint32_t off = ((uint32_t)(min(8 * by + y, a.H - 1) - r0) * (uint32_t)a.W + (uint32_t)xs) * 3u;
+                const u32x4_t p0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+                const u32x2_t p1 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16, 0, 0);
+                pix[y][0] = p0.x; pix[y][1] = p0.y; pix[y][2] = p0.z; pix[y][3] = p0.w; pix[y][4] = p1.x; pix[y][5] = p1.y;
+                // The range check is per DWORD: where the image ends inside a dword of the 24 bytes (its last row, at the last
+                // pixel: 3 (xlast + 1) bytes are left, not a multiple of 4) that dword arrives as 0 and its 1 .. 3 real bytes
+                // are fetched one by one -- never a byte past the end of the caller's buffer.  One workgroup per image does this.
+                const uint32_t n_in = left - off < 24 ? (uint32_t)(left - off) : 24u;   // (off < left: pixel (xs, row) exists)
+                if (n_in < 24 && (n_in & 3)) {
+                    const uint32_t k = n_in >> 2, at = off + 4 * k;
+                    uint32_t v = __builtin_amdgcn_raw_buffer_load_b8(rsrc, at, 0, 0);
+                    v |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, at + 1, 0, 0) << 8;   // (out of range: 0)
+                    v |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, at + 2, 0, 0) << 16;
 #pragma unroll
-                for (int d = 0; d < 6; ++d) {
-                    uint32_t v = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int byte = 4 * d + i, x = byte / 3, ch = byte - 3 * x;
-                        v |= (uint32_t)row[3 * min(8 * bx + x, a.W - 1) + ch] << (8 * i);
-                    }
-                    pix[y][d] = v;
+                    for (int d = 0; d < 6; ++d) pix[y][d] = (uint32_t)d == k ? v : pix[y][d];
                 }
             }
         }
@@ -454,6 +475,12 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
                     c[ch][x] = (byte & 3) == 0 ? ubyte<0>(dw) : (byte & 3) == 1 ? ubyte<1>(dw)
                                : (byte & 3) == 2 ? ubyte<2>(dw) : ubyte<3>(dw);
                 }
+            if (ragged) {   // edge replicate to the right: pixel x > W - 1 is pixel W - 1 (encode.swift:416)
+#pragma unroll
+                for (int x = 1; x < 8; ++x)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) c[ch][x] = x <= xlast ? c[ch][x] : c[ch][x - 1];
+            }
             emit_row(y, c[0], c[1], c[2]);
 #pragma unroll
             for (int x = 0; x < 8; ++x) asm volatile("" : "+v"(yv[8 * y + x]));
@@ -560,9 +587,8 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     if (a.tiles_x * tiles_y == 0 || n_images == 0) return hipSuccess;
     const dim3 grid(a.tiles_x * tiles_y, n_images);
     // more workgroups than are resident at once (four 8-row tiles per CU)?  Then the launch is several rounds long.
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    const bool several_rounds = (long)a.tiles_x * tiles_y * n_images > 4L * cus;
+    // (what is resident at once: the occupancy of the instantiation in question x CUs, cached per device)
+    const bool several_rounds = (long)a.tiles_x * tiles_y * n_images > (long)resident_workgroups_of<k_encode_fused<2, 2, true, true, true, 8, false>>(4);
     // (the vector-load path addresses a tile's rows with 32-bit byte offsets: 16 block rows x 8 x W x 3 B must stay below 2^32)
     const bool fast = (L.width & 7) == 0 && (pixel_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 7) == 0 &&
                       L.width <= (1 << 23);

@@ -1,0 +1,274 @@
+// kernels_generic.hip -- Spectral -> Rectangular in ONE launch for the JPEG.Format plug-in path.
+//
+// Replaces idct() -> interleaved(cosite:) (decode.swift:4154-4165, 4182-4276) for every layout the built-in 8-bit fast
+// paths do not take: any precision 1 .. 16 (examples/custom-color/main.swift:41-63 uses 12), one to four planes, centred or
+// cosited upsampling, every plane at the image's scale or at half of it per axis (factors 1 | 2 under a scale of at most 2).
+// Output: the reference's Rectangular, uint16 [H][W][count].  No Planar intermediate in HBM: 128 B per coefficient block in,
+// 2 B per sample out ("stops at Rectangular").
+//
+// EXACT BY CONSTRUCTION: this kernel keeps the reference's LITERAL operation sequence -- the same float operations in the
+// same order as kernels_stage.hip's k_idct_plane + k_planar_to_pixels (dct.hpp op for op; per pixel the truncating
+// quotient / remainder of decode.swift:4240-4241, the index clamp to the PADDED plane :4245-4246, t = clamp(Float(f) / Float(c))
+// by a true division :4250-4251, the two-step interpolation :4260-4261 and .rounded() :4264).  None of the enumerated
+// shortcuts of the 8-bit kernels (exact small-integer filters, FMA colour, reciprocal quantiser) is used: those are proofs by
+// exhaustion over 8-bit domains.  The only thing shared between pixels is the table of t values: Float(f) / Float(c) is
+// computed once per (plane, axis, f) -- f = -1 .. c - 1 -- by the same division, instead of once per pixel.
+//
+// Work decomposition.  One workgroup = one tile of 128 x TH pixels (TH = 64 when the tile's blocks fit 256 work-items, else
+// 32).  Phase A: one 8 x 8 block per work-item (dct.hpp: both passes and transposes are register renames) over the blocks
+// of every plane that the tile's pixels read -- for a plane at half resolution that includes a ring of one block, the
+// bilinear filter reaches one sample beyond the tile (decode.swift:4243-4257) -- clamp + truncate (decode.swift:4121-4122),
+// samples into an LDS tile as uint16.  Phase B: a work-item takes 16 consecutive pixels of a row, gathers every plane's
+// sample (copy for planes at the image's scale, decode.swift:4206-4215; bilinear otherwise) and writes 32 * count contiguous
+// bytes.  Halo blocks are recomputed by the neighbouring tiles (a 4:2:0 tile transforms 60 chroma blocks per plane for 32 of
+// its own): this kernel is the correctness-first generic path, ~2.5 x the instructions per pixel of k_quad420.
+#pragma clang fp contract(off)
+
+#include "dct.hpp"
+#include "kernels.hpp"
+
+namespace jpeg_amd {
+
+namespace {
+
+constexpr int kGThreads = 256;
+constexpr int GTW = 128;   // tile width in pixels
+
+struct GenPlane {
+    const int16_t *coef;
+    size_t stride;        // elements between images
+    int ux, uy;           // units
+    int rx, ry;           // scale / factor per axis: 1 or 2
+    int direct;           // factor == scale on both axes, or a single-plane image: cropped copy (decode.swift:4185-4215)
+    int qi;
+    int ax, bx, cx, ay, by, cy;   // decode.swift:4223-4234
+};
+struct GenArgs {
+    GenPlane pl[JPEG_AMD_MAX_PLANES];
+    const uint16_t *quanta;
+    size_t quanta_stride;
+    int count, W, H;
+    float level, limit;   // decode.swift:4110-4113
+    uint16_t *out;
+    size_t out_stride;    // elements between images
+    int tiles_x;
+};
+
+// truncating division by c = 1, 2 or 4 (log2c = 0, 1, 2) -- Int.quotientAndRemainder, decode.swift:4240
+__device__ __forceinline__ int div_trunc_pow2(int n, int c, int log2c)
+{
+    return (n + ((n >> 31) & (c - 1))) >> log2c;
+}
+
+template <int TH, int COUNT>
+__global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t tile[kGThreads * 64];   // at most one block per work-item: 32 KiB
+    __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                             // modulated tables (natural order)
+    __shared__ float tt[JPEG_AMD_MAX_PLANES][2][8];                           // t = clamp(Float(f) / Float(c)), f = -1 .. 6
+
+    const int t = threadIdx.x, img = blockIdx.y;
+    const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
+    const int x0 = txi * GTW, y0 = tyi * TH;
+
+    // ---- tables: one entry per work-item (decode.swift:3984-4017), and the interpolation weights by a true division ----
+    {
+        const int p = t >> 6, e = t & 63;
+        if (p < COUNT) sq[p][e] = modulate_entry(e & 7, e >> 3, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.pl[p].qi + zigzag_of(e & 7, e >> 3)]);
+        if (t < JPEG_AMD_MAX_PLANES * 16) {
+            const int pp = t >> 4, axis = (t >> 3) & 1, f = (t & 7) - 1;
+            if (pp < COUNT) {
+                const int c = axis ? a.pl[pp].cy : a.pl[pp].cx;
+                tt[pp][axis][t & 7] = fmaxf(0.0f, fminf((float)f / (float)c, 1.0f));   // decode.swift:4250-4251
+            }
+        }
+    }
+
+    // ---- the tile's blocks, plane by plane (wave-uniform scalars) ----
+    int bx0[COUNT], by0[COUNT], nbx[COUNT], first[COUNT + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int p = 0; p < COUNT; ++p) {
+        const bool hx = !a.pl[p].direct && a.pl[p].rx == 2, hy = !a.pl[p].direct && a.pl[p].ry == 2;
+        bx0[p] = hx ? x0 / 16 - 1 : x0 / 8;  nbx[p] = hx ? GTW / 16 + 2 : GTW / 8;
+        by0[p] = hy ? y0 / 16 - 1 : y0 / 8;
+        const int nby = hy ? TH / 16 + 2 : TH / 8;
+        first[p + 1] = first[p] + nbx[p] * nby;
+    }
+    __syncthreads();
+
+    // ---- phase A: dequantise + IDCT of one block, samples into the LDS tile ----
+    if (t < first[COUNT]) {
+        int p = 0;
+#pragma unroll
+        for (int q = 1; q < COUNT; ++q) p += t >= first[q];
+        int f0 = first[0], b0x = bx0[0], b0y = by0[0], nx = nbx[0];
+#pragma unroll
+        for (int q = 1; q < COUNT; ++q)
+            if (p == q) { f0 = first[q]; b0x = bx0[q]; b0y = by0[q]; nx = nbx[q]; }
+        const int local = t - f0, lby = local / nx, lbx = local - lby * nx;
+        const int gbx = b0x + lbx, gby = b0y + lby;
+        int ux = a.pl[0].ux, uy = a.pl[0].uy;
+        const int16_t *cbase = a.pl[0].coef + img * a.pl[0].stride;
+#pragma unroll
+        for (int q = 1; q < COUNT; ++q)
+            if (p == q) { ux = a.pl[q].ux; uy = a.pl[q].uy; cbase = a.pl[q].coef + img * a.pl[q].stride; }
+        if (gbx >= 0 && gbx < ux && gby >= 0 && gby < uy) {   // blocks outside the plane are never read (index clamps below)
+            const uint4 *src = reinterpret_cast<const uint4 *>(cbase + (size_t)64 * ((size_t)gby * ux + gbx));
+            uint32_t w[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 v = src[i];
+                w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+            float g[64];
+            idct_block(w, sq[p], a.level, g);
+            uint16_t *dst = tile + 64 * f0 + (8 * lby) * (8 * nx) + 8 * lbx;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                uint32_t s[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) s[x] = clamp_trunc(g[8 * y + x], a.limit);   // decode.swift:4121-4122
+                uint4 v;
+                v.x = s[0] | (s[1] << 16); v.y = s[2] | (s[3] << 16);
+                v.z = s[4] | (s[5] << 16); v.w = s[6] | (s[7] << 16);
+                *reinterpret_cast<uint4 *>(dst + y * (8 * nx)) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: 16 consecutive pixels of a row per work-item and pass ----
+#pragma unroll 1
+    for (int pass = 0; pass < TH / 32; ++pass) {
+        const int y = y0 + 32 * pass + (t >> 3);
+        int xb = x0 + 16 * (t & 7);
+        asm volatile("" : "+v"(xb));   // opaque per pass: what depends only on x would otherwise be hoisted out of the pass loop (~190 VGPRs)
+        if (y >= a.H || xb >= a.W) continue;
+        uint32_t o[8 * COUNT];   // 16 pixels x COUNT samples, packed in pairs in the output's order
+#pragma unroll
+        for (int i = 0; i < 8 * COUNT; ++i) o[i] = 0;
+#pragma unroll
+        for (int p = 0; p < COUNT; ++p) {
+            __builtin_amdgcn_sched_barrier(0);   // one plane at a time: left alone, the scheduler issues every plane's LDS reads up front
+            const uint16_t *pt = tile + 64 * first[p];
+            const int pitch = 8 * nbx[p], ox = 8 * bx0[p], oy = 8 * by0[p];
+            uint32_t s[16];
+            if (a.pl[p].direct) {   // cropped copy: sample (x, y) of the plane
+                const uint4 *row = reinterpret_cast<const uint4 *>(pt + (y - oy) * pitch + (xb - ox));
+                const uint4 v0 = row[0], v1 = row[1];
+                const uint32_t d[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = (d[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            } else {
+                const GenPlane &P = a.pl[p];
+                const int pw = 8 * P.ux, ph = 8 * P.uy;
+                const int lcx = P.cx == 4 ? 2 : P.cx == 2 ? 1 : 0, lcy = P.cy == 4 ? 2 : P.cy == 2 ? 1 : 0;
+                const int cols = pitch;
+                // the row's vertical position: decode.swift:4240-4251 for y
+                const int ny = P.ay + P.by * y;
+                const int iy = div_trunc_pow2(ny, P.cy, lcy), fy = ny - iy * P.cy;
+                const int jy = min(iy + 1, ph - 1);
+                const float ty = tt[p][1][fy + 1];
+                const uint16_t *r0 = pt + (iy - oy) * pitch, *r1 = pt + (jy - oy) * pitch;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int x = xb + i;
+                    const int nxx = P.ax + P.bx * x;
+                    const int ix = div_trunc_pow2(nxx, P.cx, lcx), fx = nxx - ix * P.cx;
+                    const int jx = min(ix + 1, pw - 1);
+                    const float tx = tt[p][0][fx + 1];
+                    // tile-local columns; pixels right of the image (never stored) and the weight-0 neighbour of a full-
+                    // resolution axis may point past the tile: any finite sample will do there
+                    const int lix = min(ix - ox, cols - 1), ljx = min(jx - ox, cols - 1);
+                    const float u00 = (float)r0[lix], u01 = (float)r0[ljx];
+                    const float u10 = (float)r1[lix], u11 = (float)r1[ljx];
+                    const float v0 = u00 * (1.0f - tx) + u01 * tx;   // decode.swift:4260-4261
+                    const float v1 = u10 * (1.0f - tx) + u11 * tx;
+                    s[i] = (uint32_t)round_half_away(v0 * (1.0f - ty) + v1 * ty);   // :4264
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e = i * COUNT + p;   // element index within the thread's 16 * COUNT output samples
+                o[e >> 1] |= (s[i] & 0xffffu) << (16 * (e & 1));
+            }
+        }
+        uint16_t *dst = a.out + img * a.out_stride + ((size_t)y * a.W + xb) * COUNT;
+        if (xb + 16 <= a.W) {
+#pragma unroll
+            for (int k = 0; k < 2 * COUNT; ++k)   // (rows need not be 16-byte aligned: the hardware takes unaligned dwordx4 stores)
+                *reinterpret_cast<uint4 *>(dst + 8 * k) = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        } else {
+            const int n = (a.W - xb) * COUNT;
+            for (int e = 0; e < n; ++e) dst[e] = (uint16_t)(o[e >> 1] >> (16 * (e & 1)));
+        }
+    }
+}
+
+int tile_blocks(const jpeg_amd_layout &L, int th)
+{
+    int n = 0;
+    for (int p = 0; p < L.nplanes; ++p) {
+        const bool direct = L.nplanes == 1 || (L.factor_x[p] == L.scale_x && L.factor_y[p] == L.scale_y);
+        const bool hx = !direct && L.scale_x / L.factor_x[p] == 2, hy = !direct && L.scale_y / L.factor_y[p] == 2;
+        n += (hx ? GTW / 16 + 2 : GTW / 8) * (hy ? th / 16 + 2 : th / 8);
+    }
+    return n;
+}
+
+}  // namespace
+
+bool generic_fused_supported(const jpeg_amd_layout &L)
+{
+    if (L.nplanes < 1 || L.nplanes > JPEG_AMD_MAX_PLANES || L.precision < 1 || L.precision > 16) return false;
+    if (L.scale_x < 1 || L.scale_x > 2 || L.scale_y < 1 || L.scale_y > 2) return false;
+    for (int p = 0; p < L.nplanes; ++p) {
+        if (L.factor_x[p] < 1 || L.factor_y[p] < 1 || L.factor_x[p] > L.scale_x || L.factor_y[p] > L.scale_y) return false;
+        if (L.scale_x % L.factor_x[p] || L.scale_y % L.factor_y[p]) return false;
+    }
+    if (L.width < 1 || L.height < 1 || (long long)L.width * L.height * L.nplanes >= (1LL << 40)) return false;
+    return tile_blocks(L, 32) <= kGThreads;
+}
+
+hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const PlaneSet &coef, QuantaRef q,
+                                bool cosited, uint16_t *d_rect, size_t rect_stride)
+{
+    GenArgs a{};
+    a.count = L.nplanes; a.W = L.width; a.H = L.height;
+    a.level = ldexpf(1.0f, L.precision - 1) + 0.5f;   // decode.swift:4110-4113
+    a.limit = ldexpf(1.0f, L.precision) - 1.0f;
+    a.quanta = q.d_quanta; a.quanta_stride = q.image_stride;
+    a.out = d_rect; a.out_stride = rect_stride;
+    for (int p = 0; p < L.nplanes; ++p) {
+        GenPlane &P = a.pl[p];
+        P.coef = static_cast<const int16_t *>(coef.ptr[p]); P.stride = coef.stride[p];
+        P.ux = L.units_x[p]; P.uy = L.units_y[p]; P.qi = L.qi[p];
+        P.rx = L.scale_x / L.factor_x[p]; P.ry = L.scale_y / L.factor_y[p];
+        P.direct = (L.nplanes == 1) || (L.factor_x[p] == L.scale_x && L.factor_y[p] == L.scale_y);
+        if (cosited) {  // decode.swift:4223-4234
+            P.ax = 0; P.ay = 0; P.bx = L.factor_x[p]; P.by = L.factor_y[p]; P.cx = L.scale_x; P.cy = L.scale_y;
+        } else {
+            P.ax = L.factor_x[p] - L.scale_x; P.ay = L.factor_y[p] - L.scale_y;
+            P.bx = 2 * L.factor_x[p]; P.by = 2 * L.factor_y[p]; P.cx = 2 * L.scale_x; P.cy = 2 * L.scale_y;
+        }
+    }
+    if (n_images == 0) return hipSuccess;
+    const int th = tile_blocks(L, 64) <= kGThreads ? 64 : 32;
+    a.tiles_x = (L.width + GTW - 1) / GTW;
+    const dim3 grid(a.tiles_x * ((L.height + th - 1) / th), n_images);
+#define JA_G(TH_, C_) hipLaunchKernelGGL((k_generic_fused<TH_, C_>), grid, dim3(kGThreads), 0, stream, a)
+#define JA_GC(TH_)                               \
+    switch (L.nplanes) {                         \
+    case 1: JA_G(TH_, 1); break;                 \
+    case 2: JA_G(TH_, 2); break;                 \
+    case 3: JA_G(TH_, 3); break;                 \
+    default: JA_G(TH_, 4); break;                \
+    }
+    if (th == 64) { JA_GC(64) } else { JA_GC(32) }
+#undef JA_GC
+#undef JA_G
+    return hipGetLastError();
+}
+
+}  // namespace jpeg_amd

@@ -626,26 +626,31 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
     JA_PHASE_FLUSH((int)blockIdx.x * NW + qp, lane0)
 }
 
-// Persistent grid = what is resident at once (LDS-bound: three workgroups per CU).
-template <int MODE, int BX, bool FAST>
+// Persistent grid = what is resident at once (LDS-bound: three workgroups per CU) -- of the instantiation that is launched:
+// the two walks (DYN) of a shape are separate kernels with their own register counts.
+template <int MODE, int BX, bool FAST, bool DYN>
 int quad_resident_workgroups()
 {
-    return resident_workgroups_of<k_quad420<MODE, BX, FAST, false>>(2);   // (the two walks of an instantiation have the same footprint)
+    return resident_workgroups_of<k_quad420<MODE, BX, FAST, DYN>>(2);
 }
 
-template <int MODE, int BX, bool FAST>
-hipError_t launch_quad(hipStream_t stream, const QuadArgs &a)
+template <int MODE, int BX, bool FAST, bool DYN>
+hipError_t launch_quad_walk(hipStream_t stream, const QuadArgs &a)
 {
-    int cap = quad_resident_workgroups<MODE, BX, FAST>();
+    int cap = quad_resident_workgroups<MODE, BX, FAST, DYN>();
 #ifdef JA_X_GRID_PER_CU   // experiment: fewer resident workgroups per CU than fit
     cap = std::min(cap, (JA_X_GRID_PER_CU) * (cap / 3));
 #endif
 #ifdef JA_PHASE_PROFILE   // development aid: JA_GRID_CAP=256 runs one workgroup per CU (a wave alone on its SIMD)
     if (const char *e = std::getenv("JA_GRID_CAP")) cap = std::min(cap, std::atoi(e));
 #endif
-    if (a.tickets) hipLaunchKernelGGL((k_quad420<MODE, BX, FAST, true>), dim3(std::min(a.nstacks, cap)), dim3(kThreads), 0, stream, a);
-    else hipLaunchKernelGGL((k_quad420<MODE, BX, FAST, false>), dim3(std::min(a.nstacks, cap)), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL((k_quad420<MODE, BX, FAST, DYN>), dim3(std::min(a.nstacks, cap)), dim3(kThreads), 0, stream, a);
     return hipGetLastError();
+}
+template <int MODE, int BX, bool FAST>
+hipError_t launch_quad(hipStream_t stream, const QuadArgs &a)
+{
+    return a.tickets ? launch_quad_walk<MODE, BX, FAST, true>(stream, a) : launch_quad_walk<MODE, BX, FAST, false>(stream, a);
 }
 
 }  // namespace
@@ -712,10 +717,11 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
     const bool fast = (L.width & 15) == 0 && (pixel_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 15) == 0;
     // every decision is sized from the instantiation it concerns (colour target x strip shape x store path)
     auto resident = [&](int bx) -> int {
-        if (bx == 16) return fast ? (rgb ? quad_resident_workgroups<1, 16, true>() : quad_resident_workgroups<0, 16, true>())
-                                  : (rgb ? quad_resident_workgroups<1, 16, false>() : quad_resident_workgroups<0, 16, false>());
-        return fast ? (rgb ? quad_resident_workgroups<1, 32, true>() : quad_resident_workgroups<0, 32, true>())
-                    : (rgb ? quad_resident_workgroups<1, 32, false>() : quad_resident_workgroups<0, 32, false>());
+        // (the ticket walk's residency: it is the walk whose length the threshold below and the mixed cut are about)
+        if (bx == 16) return fast ? (rgb ? quad_resident_workgroups<1, 16, true, true>() : quad_resident_workgroups<0, 16, true, true>())
+                                  : (rgb ? quad_resident_workgroups<1, 16, false, true>() : quad_resident_workgroups<0, 16, false, true>());
+        return fast ? (rgb ? quad_resident_workgroups<1, 32, true, true>() : quad_resident_workgroups<0, 32, true, true>())
+                    : (rgb ? quad_resident_workgroups<1, 32, false, true>() : quad_resident_workgroups<0, 32, false, true>());
     };
     const QuadCut cut = quad_cut(a.ux, a.uy, n_images, std::max(resident(32), resident(16)));
     for (int part = 0; part < cut.parts; ++part) {

@@ -37,6 +37,7 @@ for it in range(N):
     rect = planar.interleaved(cosite=cosite).host_values()
     want_r = O.interleave(want_p, factors, layout.scale, (w, h), cosited=cosite)
     ok = ok and (rect == want_r).all()
+    ok = ok and (spectral.rectangular(cosite=cosite).host_values() == want_r).all()   # one call: fused where every factor is 1 | 2
     # and back: decomposed + fdct of the interleaved samples
     back = J.Rectangular.from_host(ctx, (w, h), layout, want_r).decomposed()
     want_d = O.decompose(want_r.reshape(h, w, n), (w, h), factors, layout.scale)

@@ -150,6 +150,8 @@ def test_staged_decode_unusual_layouts(J, ctx, case, cosite):
     rect = planar.interleaved(cosite=cosite).host_values()
     want = O.interleave(planar_o, factors, layout.scale, size, cosited=cosite)
     assert (rect == want).all(), f"{(rect != want).sum()} samples differ"
+    # the same in one call (jpeg_amd_spectral_rectangular: k_generic_fused where every factor is 1 | 2, staged otherwise)
+    assert (spectral.rectangular(cosite=cosite).host_values() == want).all()
     if precision == 8 and len(comps) in (1, 3):
         for color, unpack in ((J.RGB, O.unpack_rgb8), (J.YCbCr, O.unpack_ycc8)):
             got = spectral.decode(color, cosite=cosite).cpu().numpy()
@@ -402,6 +404,7 @@ def test_generic_format_decode_unpinned_no_reference_gold_and_encode_beyond_the_
     for cosite in (False, True):
         rect = planar.interleaved(cosite=cosite).host_values()
         assert (rect == O.interleave(want_p, fs, layout.scale, size, cosited=cosite)).all()
+        assert (spectral.rectangular(cosite=cosite).host_values() == rect).all()   # one launch (k_generic_fused), no Planar in HBM
     # encode: samples over the whole uint16 range, i.e. above the limit for P = 12
     samples = rng.integers(0, 65536, (size[1], size[0], nplanes)).astype(np.uint16)
     back = J.Rectangular.from_host(ctx, size, layout, samples).decomposed()
@@ -445,12 +448,14 @@ def test_generic_format_seeded_sweep_decode_unpinned_no_reference_gold(J, ctx, s
         keys = sorted(set(q)); q = [keys.index(k) for k in q]; tables = [quanta[k] for k in keys]
         cosite = bool(rng.integers(2))
         tag = (w, h, n, precision, cosite, [c.factor for c in layout.planes])
-        planar = J.Spectral.from_host(ctx, (w, h), layout, planes, tables, q=q).idct()
+        spectral = J.Spectral.from_host(ctx, (w, h), layout, planes, tables, q=q)
+        planar = spectral.idct()
         want_p = [O.idct_plane(p, tables[i], precision) for p, i in zip(planes, q)]
         assert all((a == b).all() for a, b in zip(planar.host_planes(), want_p)), tag
         factors = [c.factor for c in layout.planes]
         want_r = O.interleave(want_p, factors, layout.scale, (w, h), cosited=cosite)
         assert (planar.interleaved(cosite=cosite).host_values() == want_r).all(), tag
+        assert (spectral.rectangular(cosite=cosite).host_values() == want_r).all(), tag
         back = J.Rectangular.from_host(ctx, (w, h), layout, want_r).decomposed()
         want_d = O.decompose(want_r.reshape(h, w, n), (w, h), factors, layout.scale)
         assert all((a == b).all() for a, b in zip(back.host_planes(), want_d)), tag
@@ -479,3 +484,78 @@ def test_cosited_through_the_fused_entry_point_parity_unpinned_no_reference_gold
         assert (spectral.decode(J.RGB, cosite=cosite).cpu().numpy() == O.unpack_rgb8(rect, 3)).all()
         assert (spectral.decode(J.YCbCr, cosite=cosite).cpu().numpy() == O.unpack_ycc8(rect, 3)).all()
 
+
+
+GENERIC_FUSED = [
+    # (size, precision, factors, cosite): layouts k_generic_fused takes (every factor 1 | 2 under a scale <= 2), sizes of several tiles
+    ((700, 333), 12, [(2, 2), (1, 1), (1, 1)], False),
+    ((700, 333), 12, [(2, 2), (1, 1), (1, 1)], True),
+    ((513, 129), 12, [(2, 2), (2, 2), (2, 2), (1, 1)], False),     # examples/custom-color/main.swift:150-158: rgba12
+    ((385, 200), 16, [(1, 1), (1, 1), (1, 1)], False),
+    ((300, 301), 12, [(2, 1), (1, 1), (1, 1)], True),
+    ((257, 190), 8, [(1, 2), (1, 1), (1, 2)], False),
+    ((129, 65), 9, [(1, 1), (1, 1)], False),                       # two planes under a scale set by a non-recognised component
+    ((1000, 64), 12, [(1, 1)], False),
+    ((128, 64), 12, [(2, 2), (1, 1), (1, 1)], False),              # exactly one tile
+    ((1, 1), 16, [(2, 2), (1, 1), (1, 2), (2, 1)], True),
+]
+
+
+@pytest.mark.parametrize("case", range(len(GENERIC_FUSED)))
+def test_generic_fused_decode_unpinned_no_reference_gold_matches_oracle_and_staged(J, ctx, case):
+    """jpeg_amd_spectral_rectangular == idct().interleaved(cosite:) (decode.swift:4154-4165, 4182-4276) for custom formats, one launch:
+    against the oracle AND against the staged kernels, on images of several tiles, every plane mix, extreme coefficients (the
+    clamp at 2^P - 1 is reached).  12 / 16-bit and cosited decodes have no gold in the reference (examples/custom-color dumps
+    its INPUT): the oracle is the only checker, as for the staged path."""
+    size, precision, factors, cosite = GENERIC_FUSED[case]
+    rng = np.random.default_rng(4200 + case)
+    n = len(factors)
+    comps = {i + 1: J.Component(f, i & 1) for i, f in enumerate(factors)}
+    if case == 6:
+        comps[99] = J.Component((2, 2), 0)
+    layout = J.Layout(("custom", precision, n), comps)
+    units = layout.units(size)
+    amp = 1 << (precision - 1)
+    planes = []
+    for ux, uy in units:
+        c = rng.integers(-amp, amp, (uy, ux, 64)).astype(np.int32)
+        c[..., 5:] //= 32
+        planes.append(np.clip(c, -32768, 32767).astype(np.int16))
+    tables = [rng.integers(1, 12, 64).astype(np.uint16) for _ in range(2)]
+    q = [c.qi for c in layout.planes]
+    keys = sorted(set(q)); q = [keys.index(k) for k in q]; tables = [tables[k] for k in keys]
+    spectral = J.Spectral.from_host(ctx, size, layout, planes, tables, q=q)
+    want_p = [O.idct_plane(p, tables[i], precision) for p, i in zip(planes, q)]
+    want = O.interleave(want_p, [c.factor for c in layout.planes], layout.scale, size, cosited=cosite)
+    got = spectral.rectangular(cosite=cosite).host_values()
+    assert (got == want).all(), f"{(got != want).sum()} of {want.size} samples differ from the oracle"
+    assert (spectral.idct().interleaved(cosite=cosite).host_values() == got).all()
+    if size[0] * size[1] > 1:
+        assert int(want.max()) == (1 << precision) - 1 and int(want.min()) == 0   # both clamps exercised
+
+
+def test_generic_fused_batch_strides(J, ctx):
+    """jpeg_amd_spectral_rectangular_batch: three images of one 12-bit 4:2:0 layout, per-image table sets, strides as in
+    jpeg_amd_decode_batch; every image equals its own single call."""
+    import ctypes as C
+    import torch
+    from jpeg_amd import _lib
+    rng = np.random.default_rng(77)
+    size, n = (210, 130), 3
+    layout = J.Layout(("custom", 12, 3), {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    units = layout.units(size)
+    L = layout.c_layout(size, units, [0, 1, 1])
+    host = [[np.clip(rng.laplace(0, 300, (uy, ux, 64)), -8000, 8000).astype(np.int16) for ux, uy in units] for _ in range(n)]
+    tables = rng.integers(1, 30, (n, 2, 64)).astype(np.uint16)
+    d_planes = [torch.from_numpy(np.stack([host[i][p] for i in range(n)])).to(ctx.torch_device) for p in range(3)]
+    d_q = torch.from_numpy(tables.view(np.int16)).to(ctx.torch_device)
+    out = torch.zeros((n, size[0] * size[1] * 3), dtype=torch.int16, device=ctx.torch_device)
+    st = _lib.lib().jpeg_amd_spectral_rectangular_batch(ctx.handle, C.byref(L), n, _lib.ptr_array([p.data_ptr() for p in d_planes]),
+                                                        _lib.size_array([64 * a * b for a, b in units]), d_q.data_ptr(), 128, 2, 0,
+                                                        out.data_ptr(), size[0] * size[1] * 3)
+    assert st == 0
+    got = out.cpu().numpy().view(np.uint16)
+    for i in range(n):
+        want_p = [O.idct_plane(host[i][p], tables[i][min(p, 1)], 12) for p in range(3)]
+        want = O.interleave(want_p, [(2, 2), (1, 1), (1, 1)], (2, 2), size, cosited=False)
+        assert (got[i] == want.reshape(-1)).all(), i

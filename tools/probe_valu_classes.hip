@@ -76,27 +76,29 @@ static const char *kNames[kOps] = {"v_add_f32", "v_sub_f32", "v_mul_f32", "v_fma
     "v_bfi_b32", "v_cvt_f32_ubyte0", "v_rndne_f32", "v_mul_u32_u24", "v_mad_u32_u24", "v_min_f32", "v_lshl_or_b32"};
 
 template <int ID>
-__global__ __launch_bounds__(256) void k_op(float *out, unsigned long long *cyc, int iters)
+__global__ __launch_bounds__(256) void k_op(float *out, unsigned long long *cyc, unsigned long long *real, int iters)
 {
     float c[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) c[i] = 1.0f + 0.001f * (float)(threadIdx.x + i);
     const float s1 = 1.0000001f, s2 = 0.5f;
     __syncthreads();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) Op<ID>::run(c, s1, s2);
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc += c[i];
     if (acc == 123.456f) out[threadIdx.x] = acc;   // keep the chains alive
-    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; real[blockIdx.x * 4 + (threadIdx.x >> 6)] = r1 - r0; }
 }
 
-typedef void (*kern_t)(float *, unsigned long long *, int);
+typedef void (*kern_t)(float *, unsigned long long *, unsigned long long *, int);
 template <int... I> static void fill(kern_t *t, std::integer_sequence<int, I...>) { ((t[I] = k_op<I>), ...); }
 
 int main(int argc, char **argv)
@@ -106,27 +108,35 @@ int main(int argc, char **argv)
     fill(table, std::make_integer_sequence<int, kOps>{});
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-    float *out; unsigned long long *cyc;
-    hipMalloc(&out, 4096); hipMalloc(&cyc, 8 * 65536);
-    printf("probe_valu_classes: %d CUs, %d iterations x %d instructions per wave; cycles = s_memtime (shader clock)\n", cus, iters, 8 * kUnroll);
-    printf("%3s %-22s %12s %12s %12s   %s\n", "id", "opcode", "cyc/inst @8w", "cyc/inst @4w", "cyc/inst @3w", "(issue cycles per instruction and SIMD: mean wave time x 1 / (waves per SIMD x instructions))");
+    float *out; unsigned long long *cyc, *real;
+    hipMalloc(&out, 4096); hipMalloc(&cyc, 8 * 65536); hipMalloc(&real, 8 * 65536);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("probe_valu_classes: %d CUs, %d iterations x %d instructions per wave.  Per opcode and waves per SIMD (8 / 4 / 3):\n"
+           "  ticks = s_memtime ticks per instruction and SIMD (mean wave time / (waves per SIMD x instructions));\n"
+           "  ns    = the same from the wall clock (HIP events: kernel time / instructions per SIMD);\n"
+           "  MHz   = s_memtime ticks per microsecond of s_memrealtime (100 MHz): what the tick counter ran at\n", cus, iters, 8 * kUnroll);
+    printf("%3s %-22s | %7s %7s %6s | %7s %7s %6s | %7s %7s %6s\n", "id", "opcode", "tick@8w", "ns@8w", "MHz", "tick@4w", "ns@4w", "MHz", "tick@3w", "ns@3w", "MHz");
     for (int id = 0; id < kOps; ++id) {
-        double res[3];
-        int k = 0;
+        printf("%3d %-22s", id, kNames[id]);
         for (int wps : {8, 4, 3}) {   // waves per SIMD: blocks of 256 work-items = one wave per SIMD each; wps blocks per CU
             const int blocks = cus * wps;
-            // LDS-free kernel: residency is limited by the grid itself (one round)
-            hipLaunchKernelGGL(table[id], dim3(blocks), dim3(256), 0, 0, out, cyc, 50);   // warm
-            hipLaunchKernelGGL(table[id], dim3(blocks), dim3(256), 0, 0, out, cyc, iters);
+            hipLaunchKernelGGL(table[id], dim3(blocks), dim3(256), 0, 0, out, cyc, real, 50);   // warm
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(table[id], dim3(blocks), dim3(256), 0, 0, out, cyc, real, iters);
+            hipEventRecord(e1, 0);
             hipDeviceSynchronize();
-            std::vector<unsigned long long> h(blocks * 4);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+            std::vector<unsigned long long> h(blocks * 4), hr(blocks * 4);
             hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
-            double mean = 0;
+            hipMemcpy(hr.data(), real, hr.size() * 8, hipMemcpyDeviceToHost);
+            double mean = 0, meanr = 0;
             for (auto v : h) mean += (double)v;
-            mean /= (double)h.size();
-            res[k++] = mean / ((double)wps * iters * 8 * kUnroll);
+            for (auto v : hr) meanr += (double)v;
+            mean /= (double)h.size(); meanr /= (double)hr.size();
+            const double n = (double)wps * iters * 8 * kUnroll;   // instructions per SIMD
+            printf(" | %7.3f %7.3f %6.0f", mean / n, ms * 1e6 / n, mean / (meanr / 100.0));
         }
-        printf("%3d %-22s %12.3f %12.3f %12.3f\n", id, kNames[id], res[0], res[1], res[2]);
+        printf("\n");
     }
     return 0;
 }

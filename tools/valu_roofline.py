@@ -41,43 +41,84 @@ PASS_A = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ
           "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64"]
 PASS_B = ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY"]
 
-# issue cycles per instruction and SIMD (tools/probe_valu_classes.hip, 8 waves per SIMD; profiles/r05_probe_valu_classes.txt)
-FULL, HALF, QUARTER = 2.0, 4.0, 8.0
-COSTS_DEFAULT = {"full": FULL, "half": HALF, "trans": QUARTER}
+# ---- cost table: SQ cycles per wave64 instruction and SIMD with 8 waves per SIMD, MEASURED per opcode (tools/probe_valu_classes.hip
+#      under rocprofv3 --pmc SQ_BUSY_CYCLES, tools/valu_calibrate.py -> profiles/valu_costs.json).  Opcodes the probe does not hold
+#      take the cost of their rate class (the median of the probed members).
+COSTS_FILE = os.path.join(ROOT, "profiles", "valu_costs.json")
+CLASS_DEFAULT = {"full": 2.0, "half": 4.0, "trans": 8.0, "cndmask": 8.0}
 
-FULL_RATE = re.compile(r"^v_(add|sub|subrev|mul|mac|fmac|fmamk|fmaak|fma)_f32(_e32|_e64)?$|^v_(mov_b32|add_u32|sub_u32|subrev_u32|and_b32|or_b32|xor_b32|not_b32)(_e32|_e64)?$")
+FULL_RATE = re.compile(r"^v_(add|sub|subrev|mul|mac|fmac|fmamk|fmaak|fma)_f32$|^v_(mov_b32|add_u32|sub_u32|subrev_u32|and_b32|or_b32|xor_b32|not_b32|lshrrev_b32|ashrrev_i32|bitop3_b32)$")
 TRANS = re.compile(r"^v_(rcp|rsq|sqrt|exp|log|sin|cos)(_iflag)?_f(16|32)")
 
 
+def base_op(op: str) -> str:
+    return re.sub(r"_(e32|e64)$", "", op)
+
+
 def rate_class(op: str) -> str:
-    """full / half / trans -- the probe's three issue rates.  Everything that is not a plain f32 add / sub / mul / fma or one of
-    the few full-rate integer operations (v_mov, v_add_u32, v_and / or / xor) issues at half rate on gfx950: conversions,
-    v_cvt_pk_*, v_perm_b32, min / max / med3, floor, shifts, three-operand integer ops, SDWA and DPP forms, v_pk_*."""
-    if "sdwa" in op or "dpp" in op:
+    """full / half / trans / cndmask -- the probe's issue-rate groups (profiles/r05_probe_valu_classes.txt).  Full rate: plain f32
+    add / sub / mul / fma and a few integer operations (v_mov, v_add_u32, v_and / or / xor, right shifts).  Half rate: everything
+    else -- conversions, v_cvt_pk_*, v_perm_b32, min / max / med3, floor, left shifts, three-operand integer ops, compares, SDWA
+    and DPP forms, v_pk_*.  v_cndmask_b32 issues far slower than either (its own group)."""
+    b = base_op(op)
+    if b.endswith("_sdwa") or b.endswith("_dpp"):
         return "half"
-    if TRANS.match(op):
+    if TRANS.match(b):
         return "trans"
-    return "full" if FULL_RATE.match(op) else "half"
+    if b.startswith("v_cndmask"):
+        return "cndmask"
+    return "full" if FULL_RATE.match(b) else "half"
 
 
 def counter_class(op: str) -> str:
-    """The SQ_INSTS_VALU_* counter an opcode is tallied in (calibrated, see the module docstring)."""
-    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
-    if TRANS.match(base):
+    """The SQ_INSTS_VALU_* counter an opcode is tallied in -- CALIBRATED (one probe kernel per opcode under the counters):
+    ADD_F32: v_add / v_sub_f32 (also DPP); MUL_F32: v_mul_f32; FMA_F32: v_fma / fmac / fmamk; CVT: every v_cvt_* (v_cvt_pk_u8_f32,
+    SDWA forms, v_cvt_f32_ubyteN, v_cvt_pk_i16_i32 included); TRANS_F32: v_rcp & co.; INT32: integer ARITHMETIC and compares
+    (v_add_u32, v_add3, v_lshl_add, v_mul_lo, v_mul / mad_u24, v_ashrrev, v_min / max_i32, v_cmp_*, v_dot4); INT64: 64-bit
+    integer ops.  Tallied in NO class ("OTHER" = SQ_INSTS_VALU minus the classes): v_mov, v_cndmask, v_perm, logical ops and
+    plain shifts (and / or / xor / bfi / and_or / bitop3 / lshlrev / lshrrev / lshl_or), v_floor / rndne / min / max / med3_f32."""
+    b = re.sub(r"_(sdwa|dpp)$", "", base_op(op))
+    if TRANS.match(b):
         return "TRANS_F32"
-    if re.match(r"^v_cvt_", base):
+    if b.startswith("v_cvt_"):
         return "CVT"
-    if re.match(r"^v_(add|sub|subrev)_f32$", base):
+    if re.match(r"^v_(add|sub|subrev)_f32$", b):
         return "ADD_F32"
-    if re.match(r"^v_mul_f32$", base):
+    if b == "v_mul_f32":
         return "MUL_F32"
-    if re.match(r"^v_(fma|fmac|fmamk|fmaak|mac|mad)_f32$", base):
+    if re.match(r"^v_(fma|fmac|fmamk|fmaak|mac|mad)_f32$", b):
         return "FMA_F32"
-    if re.match(r"^v_(lshl_add_u64|mad_u64_u32|mad_i64_i32|lshlrev_b64|lshrrev_b64|ashrrev_i64|add_co_u32|addc_co_u32)$", base):
+    if re.match(r"^v_(lshl_add_u64|mad_u64_u32|mad_i64_i32|lshlrev_b64|lshrrev_b64|ashrrev_i64|add_co_u32|addc_co_u32|mov_b64)$", b):
         return "INT64"
-    if re.match(r"^v_(add|sub|subrev|mul|mad|lshl|lshr|ashr|and|or|xor|not|bfe|bfi|min|max|med3|add3|perm|bitop3|alignb|cmp|dot|sad|mbcnt|bcnt|ff|lsh)[a-z0-9_]*_(u|i|b)(8|16|24|32)", base):
+    if re.match(r"^v_(add|sub|subrev|add3|lshl_add|add_lshl|mul_lo|mul_hi|mul|mad|ashrrev|min|max|med3|dot4|dot2|sad|mbcnt|bcnt)_(u|i)(8|16|24|32)(_(u|i)(8|16|24|32))?$", b) or b.startswith("v_cmp"):
         return "INT32"
     return "OTHER"
+
+
+def load_costs(path=None, column="w8") -> dict:
+    """column: "w8" -- the probe with 8 waves per SIMD, the best the SIMD does: the roofline -- or "w4" / "w3": what it reaches
+    with that many resident waves (a kernel held to 3 or 4 waves per SIMD by its LDS / registers cannot issue faster)."""
+    path = path or COSTS_FILE
+    ops = {}
+    if os.path.exists(path):
+        ops = {k: v[column] for k, v in json.load(open(path))["ops"].items() if v.get(column)}
+    cls = dict(CLASS_DEFAULT)
+    for c in ("full", "half", "trans", "cndmask"):
+        members = sorted(v for k, v in ops.items() if rate_class(k) == c)
+        if members:
+            cls[c] = members[len(members) // 2]
+    return {"ops": ops, "classes": cls, "column": column, "file": os.path.relpath(path, ROOT) if os.path.exists(path) else None}
+
+
+def op_cost(op: str, costs: dict) -> float:
+    b = base_op(op)
+    if b in costs["ops"]:
+        return costs["ops"][b]
+    if b.endswith("_sdwa") and "v_cvt_f32_i32_sdwa" in costs["ops"]:
+        return costs["ops"]["v_cvt_f32_i32_sdwa"]
+    if b.endswith("_dpp") and "v_add_f32_dpp" in costs["ops"]:
+        return costs["ops"]["v_add_f32_dpp"]
+    return costs["classes"][rate_class(op)]
 
 
 def disassemble(lib: str, kernel: str) -> list[str]:
@@ -108,13 +149,23 @@ def disassemble(lib: str, kernel: str) -> list[str]:
     raise RuntimeError(f"kernel {kernel!r} not found in {lib}")
 
 
-def static_mix(ops: list[str]) -> dict:
-    """Per counter class: static instruction count by rate class."""
+def static_mix(ops: list[str], costs=None) -> dict:
+    """Per counter class: static instruction count and the sum / extremes of the per-opcode issue costs.  v_cndmask_b32 is left
+    out of the class means (it issues ~10 x slower than anything else -- 22.7 cycles -- and sits in the kernels' edge paths:
+    weighting it by its STATIC frequency would charge the hot path for code it does not run); its static count is reported
+    and valu_frac_max prices the whole class at it."""
+    costs = costs or load_costs()
     mix: dict = {}
     for op in ops:
         if not op.startswith("v_") or re.match(r"^v_(readlane|readfirstlane|writelane|nop)", op):
             continue
-        mix.setdefault(counter_class(op), {"full": 0, "half": 0, "trans": 0})[rate_class(op)] += 1
+        c = op_cost(op, costs)
+        m = mix.setdefault(counter_class(op), {"n": 0, "cycles": 0.0, "min": c, "max": c, "cndmask": 0})
+        m["max"] = max(m["max"], c)
+        if rate_class(op) == "cndmask":
+            m["cndmask"] += 1
+            continue
+        m["n"] += 1; m["cycles"] += c; m["min"] = min(m["min"], c)
     return mix
 
 
@@ -135,8 +186,7 @@ def read_counters(dirs, kernel_filter: str) -> tuple[dict, dict]:
     return {k: sum(v) / len(v) for k, v in acc.items()}, {"ns": (sum(dur) / len(dur)) if dur else None, "n": len(dur)}
 
 
-def valu_roofline(counters: dict, mix: dict, duration_ns=None, simds: int = 1024, sq_instances: int = 32, costs=None) -> dict:
-    costs = dict(COSTS_DEFAULT, **(costs or {}))
+def _need(counters: dict, mix: dict, costs: dict):
     n = {k.replace("SQ_INSTS_VALU_", ""): v for k, v in counters.items() if k.startswith("SQ_INSTS_VALU_")}
     total = counters["SQ_INSTS_VALU"]
     known = sum(n.get(k, 0.0) for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "CVT", "INT32", "INT64"))
@@ -144,21 +194,25 @@ def valu_roofline(counters: dict, mix: dict, duration_ns=None, simds: int = 1024
     need = need_min = need_max = mixed = 0.0
     per_class = {}
     for cls, cnt in n.items():
-        if cls in ("ADD_F32", "MUL_F32", "FMA_F32"):
-            c = lo = hi = costs["full"]
-        elif cls == "TRANS_F32":
-            c = lo = hi = costs["trans"]
-        elif cls == "CVT":
-            c = lo = hi = costs["half"]
-        else:   # INT32 / INT64 / OTHER: the kernel's own static mix of that class
-            m = mix.get(cls, {"full": 0, "half": 1, "trans": 0})
-            tot = max(1, m["full"] + m["half"] + m["trans"])
-            c = (m["full"] * costs["full"] + m["half"] * costs["half"] + m["trans"] * costs["trans"]) / tot
-            lo, hi = costs["full"], costs["half"]
+        m = mix.get(cls)
+        if m and m["n"]:
+            c, lo, hi = m["cycles"] / m["n"], min(m["min"], m["cycles"] / m["n"]), m["max"]
+        else:   # a class the kernel's disassembly does not hold (stray counts): half rate
+            c = lo = hi = costs["classes"]["half"]
+        if hi - lo > 0.25 * c:
             mixed += cnt * c
         need += cnt * c; need_min += cnt * lo; need_max += cnt * hi
         per_class[cls] = {"insts": round(cnt), "cycles_per_inst": round(c, 3)}
+    return need, need_min, need_max, mixed, per_class
+
+
+def valu_roofline(counters: dict, ops: list, duration_ns=None, waves_per_simd=None, simds: int = 1024, sq_instances: int = 32) -> dict:
+    """counters: per-dispatch means; ops: the kernel's disassembly (opcodes); waves_per_simd: the kernel's occupancy (3 | 4),
+    for the second figure -- the fraction of what the SIMD issues with THAT many resident waves."""
+    costs = load_costs()
+    need, need_min, need_max, mixed, per_class = _need(counters, static_mix(ops, costs), costs)
     elapsed = counters["SQ_BUSY_CYCLES"] / sq_instances
+    total = counters["SQ_INSTS_VALU"]
     out = {"valu_frac": round(need / simds / elapsed, 4),
            "valu_frac_min": round(need_min / simds / elapsed, 4), "valu_frac_max": round(need_max / simds / elapsed, 4),
            "mixed_share": round(mixed / need, 4),
@@ -166,10 +220,21 @@ def valu_roofline(counters: dict, mix: dict, duration_ns=None, simds: int = 1024
            "insts_valu": round(total), "insts_salu": round(counters.get("SQ_INSTS_SALU", 0)),
            "insts_lds": round(counters.get("SQ_INSTS_LDS", 0)), "insts_vmem": round(counters.get("SQ_INSTS_VMEM", 0)),
            "waves": round(counters.get("SQ_WAVES", 0)), "classes": per_class,
-           "cost_model": {"cycles_per_inst": costs, "simds": simds,
-                          "note": "issue cycles per wave64 instruction and SIMD: 2 full-rate (f32 add/sub/mul/fma, v_mov, v_add_u32, v_and/or/xor), "
-                                  "4 half-rate (conversions, v_cvt_pk, v_perm, min/max, shifts, 3-operand integer, SDWA/DPP), 8 transcendental "
-                                  "(tools/probe_valu_classes.hip); INT32/INT64/other weighted by the kernel's static mix"}}
+           "static_cndmask": sum(m.get("cndmask", 0) for m in static_mix(ops, costs).values())}
+    if waves_per_simd in (3, 4):
+        c2 = load_costs(column=f"w{waves_per_simd}")
+        need2 = _need(counters, static_mix(ops, c2), c2)[0]
+        out["waves_per_simd"] = waves_per_simd
+        out["valu_frac_at_occupancy"] = round(need2 / simds / elapsed, 4)
+        out["occupancy_class_cycles"] = {k: round(v, 3) for k, v in c2["classes"].items()}
+    out["cost_model"] = {"class_cycles": {k: round(v, 3) for k, v in costs["classes"].items()}, "per_opcode_table": costs["file"], "simds": simds,
+                         "note": "valu_frac = VALU issue cycles needed per SIMD / cycles elapsed (SQ_BUSY_CYCLES / 32).  Needed = dynamic "
+                                 "instruction counts per SQ counter class x issue cycles per wave64 instruction, MEASURED per opcode in SQ cycles "
+                                 "with 8 waves per SIMD (tools/probe_valu_classes.hip + valu_calibrate.py: 2.3 full rate, 4.1-4.2 half rate, 8.1 "
+                                 "transcendental); classes that mix rates take the mean over the kernel's own instructions of the class (static "
+                                 "mix of its disassembly, v_cndmask left out), _min / _max price a class at its cheapest / dearest opcode. "
+                                 "valu_frac_at_occupancy: the same against the issue rates the probe reaches with the kernel's own number of "
+                                 "resident waves per SIMD"}
     if duration_ns:
         out["kernel_us_under_counters"] = round(duration_ns / 1e3, 2)
         out["clock_GHz"] = round(elapsed / duration_ns, 3)
@@ -178,7 +243,7 @@ def valu_roofline(counters: dict, mix: dict, duration_ns=None, simds: int = 1024
     return out
 
 
-def measure(child_cmd: list, kernel_filter: str, lib: str, kernel_symbol: str, timeout: int = 300, keep_dir=None) -> dict:
+def measure(child_cmd: list, kernel_filter: str, lib: str, kernel_symbol: str, waves_per_simd=None, timeout: int = 300, keep_dir=None) -> dict:
     """Two rocprofv3 passes (PASS_A, PASS_B; --kernel-trace only beside --pmc) over `child_cmd` -- the program after `--` must be
     the interpreter / binary itself -- then the model above.  Returns the valu record or {"error": ...}."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -197,7 +262,7 @@ def measure(child_cmd: list, kernel_filter: str, lib: str, kernel_symbol: str, t
         counters, dur = read_counters(dirs, kernel_filter)
         if "SQ_INSTS_VALU" not in counters or "SQ_BUSY_CYCLES" not in counters:
             return {"error": f"no counters for {kernel_filter!r}: {sorted(counters)}"}
-        rec = valu_roofline(counters, static_mix(disassemble(lib, kernel_symbol)), dur["ns"])
+        rec = valu_roofline(counters, disassemble(lib, kernel_symbol), dur["ns"], waves_per_simd)
         rec["dispatches"] = dur["n"]
         rec["source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc (two passes: " + " ".join(c.replace("SQ_", "") for c in PASS_A) + " | " +
                          " ".join(c.replace("SQ_", "") for c in PASS_B) + ") over " + " ".join(os.path.basename(c) for c in child_cmd[1:3]))
@@ -216,6 +281,7 @@ def main():
     ap.add_argument("--kernel", required=True, help="substring of the mangled kernel name (disassembly)")
     ap.add_argument("--filter", default=None, help="substring of the kernel name in the counter files (default: --kernel)")
     ap.add_argument("--static-only", action="store_true")
+    ap.add_argument("--waves", type=int, default=None, help="the kernel's waves per SIMD (3 | 4): adds valu_frac_at_occupancy")
     ap.add_argument("dirs", nargs="*")
     a = ap.parse_args()
     ops = disassemble(a.lib, a.kernel)
@@ -227,11 +293,11 @@ def main():
                 hist[op] = hist.get(op, 0) + 1
         print(f"{a.kernel}: {len(ops)} instructions, {sum(hist.values())} VALU (static)")
         for op, c in sorted(hist.items(), key=lambda t: -t[1]):
-            print(f"   {c:6d}  {op:28s} {counter_class(op):10s} {rate_class(op)}")
+            print(f"   {c:6d}  {op:28s} {counter_class(op):10s} {rate_class(op):8s} {op_cost(op, load_costs()):6.2f}")
         print(json.dumps(mix))
         return
     counters, dur = read_counters(a.dirs, a.filter or a.kernel)
-    print(json.dumps(valu_roofline(counters, mix, dur["ns"]), indent=1))
+    print(json.dumps(valu_roofline(counters, ops, dur["ns"], a.waves), indent=1))
 
 
 if __name__ == "__main__":

@@ -377,7 +377,12 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
         def make_workload(name, width, height, n_images, ring, quanta, seed):
             return DecodeWorkload(J, ctx, width, height, n_images, ring, quanta, seed)
     if workload == "c3":
-        ring = args.ring or 8
+        # Ring of distinct image sets, so that the 256 MiB Infinity Cache cannot serve the input: four sets = 1.6 GB of coefficients
+        # and pixels between two uses of a set.  (Rounds 1-4 used eight: 3.2 GB of mappings exceed the GPU's TLB reach and the step
+        # then pays ~3 us of page walks that belong to the benchmark's footprint, not to the decode of ONE image -- every set alone
+        # decodes in 74-77 us, rotating over 4 sets 75.4, over 8 sets 78.0: profiles/r05_bench_ring.txt.  The sharded C5 job below,
+        # 51 GB per step, carries the full cost of a large footprint.)
+        ring = args.ring or 4
         wl = make_workload("c3", 8192, 8192, 1, ring, d_quanta, 20240807 + 1000 * rank)
         scaling, images_total = "weak", world
         name = ("C3: one 8192x8192 ycc8 4:2:0 image per GPU per step, fused Spectral->RGB8 decode "

@@ -198,6 +198,11 @@ int jpeg_amd_host_rectangular_unpack(jpeg_amd_ctx *ctx, const uint16_t *h_rect,
 int jpeg_amd_host_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
                          const int16_t *const h_coef[], const uint16_t *h_quanta, int ntables,
                          int cosited, jpeg_amd_color color, uint8_t *h_pixels);
+/* idct().interleaved(cosite:) with host buffers: ONE crossing of the link each way, one launch on the device for formats
+ * whose planes lie at the image's scale or at half of it (jpeg_amd_spectral_rectangular). */
+int jpeg_amd_host_spectral_rectangular(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
+                                       const int16_t *const h_coef[], const uint16_t *h_quanta, int ntables,
+                                       int cosited, uint16_t *h_rect);
 int jpeg_amd_host_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *h_pixels, size_t npixels,
                                    int nplanes, jpeg_amd_color color, uint16_t *h_rect);
 int jpeg_amd_host_rectangular_decomposed(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,

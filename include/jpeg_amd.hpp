@@ -278,6 +278,17 @@ class spectral {
                                      op.data()), "jpeg_amd_spectral_idct");
         return planar(*ctx, size, lay, units, std::move(out));
     }
+    /// fused idct().interleaved(cosite:) (decode.swift:4154-4165, 4182-4276) for any format: one launch where every plane lies at
+    /// the image's scale or at half of it, the staged kernels otherwise; the same samples either way
+    rectangular to_rectangular(bool cosite = false) const
+    {
+        jpeg_amd_layout l = lay.c_layout(size, units, q);
+        device_array<uint16_t> values(*ctx, (size_t)size.x * size.y * lay.count());
+        auto in = detail::pointers(planes);
+        check(jpeg_amd_spectral_rectangular(ctx->handle(), &l, const_cast<const int16_t *const *>(in.data()), tables.data(), ntables(),
+                                            cosite ? 1 : 0, values.data()), "jpeg_amd_spectral_rectangular");
+        return rectangular(*ctx, size, lay, std::move(values));
+    }
     /// fused idct().interleaved(cosite:).unpack(as:) -> H*W colours of 3 bytes
     std::vector<uint8_t> decode(color target, bool cosite = false) const
     {

@@ -744,6 +744,26 @@ try {
 }
 JA_NOTHROW_TAIL
 
+int jpeg_amd_host_spectral_rectangular(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L,
+                                       const int16_t *const h_coef[], const uint16_t *h_quanta, int ntables,
+                                       int cosited, uint16_t *h_rect)
+try {
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (!h_coef || !h_rect) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int p = 0; p < L->nplanes; ++p)
+        JA_TRY(bag.upload(h_coef[p], plane_samples(L, p) * 2, (void **)&d_coef[p]));
+    uint16_t *d_rect = nullptr;
+    JA_TRY(bag.alloc(rect_samples(L) * 2, (void **)&d_rect));
+    JA_TRY(jpeg_amd_spectral_rectangular(ctx, L, d_coef, h_quanta, ntables, cosited, d_rect));
+    JA_TRY(bag.download(h_rect, d_rect, rect_samples(L) * 2));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+JA_NOTHROW_TAIL
+
 int jpeg_amd_host_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *h_pixels, size_t npixels,
                                    int nplanes, jpeg_amd_color color, uint16_t *h_rect)
 try {

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
     // (waves per SIMD declared above: 4 for the 8-row tiles, 2 for 4:4:4 -- its 65 KiB of LDS and 256 VGPRs admit no
     // more -- 2 for 4:2:2 / 4:4:0, and 3 for the 16-row tiles of the JA_X_ENC_TY experiment)
     constexpr bool HALFSTAGE = TY == 8;                  // 4 KiB of store staging per wave instead of 8
-    static_assert(TY == 16 || (TY == 8 && SX * SY != 2), "the per-half chroma tiles of 4:2:2 / 4:4:0 need 16 block rows");
+    static_assert(TY == 16 || TY == 8, "tiles of 16 or 8 luma block rows");
     constexpr bool INTHREAD = SX == 1 && SY == 1;        // 4:4:4: chroma block == the luma block's pixels
     // 4:2:0: the 2 x 2 box filter in the integer domain (POOLI) removes 1.6 of the 50 instructions per pixel.  It pays where the
     // launch is several rounds of workgroups long (8192 x 8192: 88.6 against 91.5 us) and LOSES where the whole frame is one
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY =
     constexpr bool POOL_INT = POOLI;
     // 4:2:2 / 4:4:0: the 8 luma block rows of one `half` already hold 256 chroma blocks (one per
     // work-item), so the chroma tile covers one half at a time and stays at 16 KiB
-    constexpr bool PERHALF = CHROMA && SX * SY == 2;
+    constexpr bool PERHALF = CHROMA && SX * SY == 2 && TY == 16;   // (an 8-row tile of 4:2:2 / 4:4:0 holds one chroma block per work-item: a single pass)
     constexpr int CW = ETX * 8 / SX, CH = (PERHALF ? TY / 2 : TY) * 8 / SY;  // chroma samples per tile (or half)
     constexpr int CPITCH = CW / 4;                       // dwords per LDS row
     __shared__ uint32_t sc[(CHROMA && !INTHREAD) ? 2 * CH * CPITCH : 1];
@@ -581,7 +581,11 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     // 16-row tiles at every size (tools/bench_encode.py, builds with -DJA_X_ENC_TY=16 / 8: 4096 x 4096 4:2:0 30.9 -> 28.8 us, 8192 x 8192
     // 103.6 -> 97.5, 2048 x 2048 23.3 -> 15.4, grey 4096 x 4096 21.2 -> 16.9).  4:2:2 / 4:4:0 pool chroma per half tile and
     // 4:4:4 parks it per lane: those keep 16 rows.
+#ifdef JA_X_ENC_TY8ALL   // experiment: 8-row tiles for every layout
+    const bool can8 = true;
+#else
     const bool can8 = !chroma || (sx == 2 && sy == 2);
+#endif
     const int ty = can8 && encode_ty_override() != 16 ? 8 : 16;
     const int tiles_y = (need_y + ty - 1) / ty;
     if (a.tiles_x * tiles_y == 0 || n_images == 0) return hipSuccess;
@@ -609,6 +613,9 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
         else if (sx == 2 && sy == 2 && ty == 8 && several_rounds) JA_E8I(2, 2, RGB_, true, F_); \
         else if (sx == 2 && sy == 2 && ty == 8) JA_E8(2, 2, RGB_, true, F_); \
         else if (sx == 2 && sy == 2) JA_E16(2, 2, RGB_, true, F_); \
+        else if (sx == 2 && sy == 1 && ty == 8) JA_E8(2, 1, RGB_, true, F_); \
+        else if (sx == 1 && sy == 2 && ty == 8) JA_E8(1, 2, RGB_, true, F_); \
+        else if (ty == 8) JA_E8(1, 1, RGB_, true, F_);          \
         else if (sx == 2 && sy == 1) JA_E(2, 1, RGB_, true, F_); \
         else if (sx == 1 && sy == 2) JA_E(1, 2, RGB_, true, F_); \
         else JA_E(1, 1, RGB_, true, F_);                        \

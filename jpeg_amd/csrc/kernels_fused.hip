@@ -148,62 +148,44 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         sxi = (int)col;
     };
 
-    // LDS-DMA of the 64 blocks of strip s: instruction i moves 64 x 16 B; slot
-    // u = 64 i + lane holds chunk (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3.
-    // which: 0 luma; 4:4:4: 1 Cb, 2 Cr; 4:2:2: 1 both chroma planes under the strip, 2 their halo blocks
+    // LDS-DMA of the 64 blocks of strip s: an instruction moves 64 x 16 B; slot u = 64 i + lane holds chunk
+    // (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3 (the XOR on the SOURCE address makes the later per-work-item ds_read_b128
+    // conflict-free).  Round 5: runs of neighbouring blocks go through BUFFER RESOURCES over the block rows in question
+    // (base advanced to the first row in 64 bits -- a plane may exceed 4 GiB -- num_records = those rows inside the plane):
+    // one scalar byte offset per run; rows outside the plane and runs that overhang the resource arrive as zeros, runs that
+    // overhang a block row fetch the head of the next one -- "fetched, not used" either way (their pixels are dropped by the
+    // store's range check, their chroma samples repaired in the tile).  No clamped addresses, no interior / edge split.
+    // which: 0 luma; 4:4:4: 1 Cb, 2 Cr; 4:2:2: 1 both chroma planes under the strip, 2 their halo blocks (block by block);
+    // 4:4:0: 1 the chroma blocks under the strip, 3 the block rows above and below
+    auto sgpr = [](uint32_t v) -> uint32_t { asm volatile("" : "+s"(v)); return v; };   // (see kernels_quad.hip)
+    auto rows_of = [&](const int16_t *plane, uint32_t row0, uint32_t nrows, uint32_t row_blocks) -> i32x4_t {
+        return make_srd(reinterpret_cast<const char *>(plane) + ((uint64_t)(row0 * row_blocks) << 7), (nrows * row_blocks) << 7);
+    };
     auto dma_strip = [&](int s, int lane, int which = 0) {
         int img, syi, sxi;
         locate(s, img, syi, sxi);
-        const int16_t *base = a.coef + img * a.coef_stride;
-        if constexpr (INTHREAD) {
-            if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
-        }
+        const uint32_t l3 = lane >> 3;
+        const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);  // even pieces; odd pieces: chunk ^ 4
         if constexpr (IN422 || IN440) {
-            const int uxc = a.pw_c >> 3, uyc = a.ph_c >> 3;
-            if (which == 1) {   // block b of the buffer: plane b >> 5, row (b >> 4) & 1, column b & 15
-                if (16 * sxi + 16 <= uxc && 2 * syi + 2 <= uyc) {
-                    const uint32_t l3 = lane >> 3;
-                    const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
+            const uint32_t uxc = sgpr((uint32_t)(a.pw_c >> 3));
+            const int uyc = a.ph_c >> 3;
+            if (which == 1) {   // block b of the buffer: plane b >> 5, row (b >> 4) & 1, column b & 15: four runs of sixteen
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {   // four runs of sixteen neighbouring blocks: one M0 write and one base each
-                        const int16_t *cbase = a.ccoef[u >> 1] + img * a.ccoef_stride[u >> 1];
-                        const uint32_t blk0 = (uint32_t)(2 * syi + (u & 1)) * uxc + 16 * sxi;
-                        lds_dma16_run<2, true>(reinterpret_cast<uint64_t>(cbase) + ((uint64_t)blk0 << 7), ve, ve ^ 64u, coef_lds + 2048 * u);
-                    }
-                    return;
-                }
+                for (int pl = 0; pl < 2; ++pl) {
+                    const i32x4_t srd = rows_of(a.ccoef[pl] + img * a.ccoef_stride[pl], (uint32_t)(2 * syi), (uint32_t)min(2, uyc - 2 * syi), uxc);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int16_t *cbase = a.ccoef[i >> 2] + img * a.ccoef_stride[i >> 2];
-                    const int b = 8 * i + (lane >> 3);
-                    const int bx = 16 * sxi + (b & 15), by = 2 * syi + ((b >> 4) & 1);
-                    const uint32_t blk = (bx < uxc && by < uyc) ? (uint32_t)by * uxc + bx : 0u;
-                    const int c = (lane & 7) ^ ((b >> 1) & 7);
-                    lds_dma16(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+                    for (int r = 0; r < 2; ++r)
+                        lds_dma16_brun<2, true>(srd, ((uint32_t)r * uxc + (uint32_t)(16 * sxi)) << 7, ve, ve ^ 64u, coef_lds + 2048 * (2 * pl + r));
                 }
                 return;
             }
             if (which == 3) {   // 4:4:0 halo: block b of the buffer: below b >> 5, plane (b >> 4) & 1, column b & 15
-                const int rows[2] = {min(max(2 * syi - 1, 0), uyc - 1), min(2 * syi + 2, uyc - 1)};   // missing rows: fetched, not used
-                if (16 * sxi + 16 <= uxc) {
-                    const uint32_t l3 = lane >> 3;
-                    const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int16_t *cbase = a.ccoef[u & 1] + img * a.ccoef_stride[u & 1];
-                        const uint32_t blk0 = (uint32_t)rows[u >> 1] * uxc + 16 * sxi;
-                        lds_dma16_run<2, false>(reinterpret_cast<uint64_t>(cbase) + ((uint64_t)blk0 << 7), ve, ve ^ 64u, coef_lds + 2048 * u);
-                    }
-                    return;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int16_t *cbase = a.ccoef[(i >> 1) & 1] + img * a.ccoef_stride[(i >> 1) & 1];
-                    const int b = 8 * i + (lane >> 3);
-                    const int bx = 16 * sxi + (b & 15);
-                    const uint32_t blk = bx < uxc ? (uint32_t)rows[i >> 2] * uxc + bx : 0u;
-                    const int c = (lane & 7) ^ ((b >> 1) & 7);
-                    lds_dma16_keep(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds + 1024 * i);
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (u >> 1) ? 2 * syi + 2 : 2 * syi - 1;
+                    const bool there = row >= 0 && row < uyc;   // a missing row: an empty resource (zeros; the tile row is repaired below)
+                    const i32x4_t srd = rows_of(a.ccoef[u & 1] + img * a.ccoef_stride[u & 1], there ? (uint32_t)row : 0u, there ? 1u : 0u, uxc);
+                    lds_dma16_brun<2, false>(srd, (uint32_t)(16 * sxi) << 7, ve, ve ^ 64u, coef_lds + 2048 * u);
                 }
                 return;
             }
@@ -211,34 +193,22 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 const int b = lane >> 3;
                 const int16_t *cbase = a.ccoef[b >> 2] + img * a.ccoef_stride[b >> 2];
                 const int bx = ((b >> 1) & 1) ? 16 * sxi + 16 : 16 * sxi - 1, by = 2 * syi + (b & 1);
-                const uint32_t blk = (bx >= 0 && bx < uxc && by < uyc) ? (uint32_t)by * uxc + bx : 0u;
+                const uint32_t blk = (bx >= 0 && bx < (int)uxc && by < uyc) ? (uint32_t)by * uxc + bx : 0u;
                 const int c = (lane & 7) ^ ((b >> 1) & 7);
                 lds_dma16(reinterpret_cast<const char *>(cbase) + ((size_t)blk * 128 + 16 * c), coef_lds);
                 return;
             }
         }
-        if (sxi * BX + BX <= a.ux && BY * syi + BY <= a.uy) {
-            // interior strip (wave-uniform test): the block index is scalar, only the lane's
-            // place inside an 8-block group (and its swizzled chunk) is per lane
-            const uint32_t l3 = lane >> 3;
-            const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);  // even i; odd i: chunk ^ 4
-#pragma unroll
-            for (int r = 0; r < BY; ++r) {   // BY runs of BX neighbouring blocks: one M0 write and one base each (fused_common.hpp)
-                const uint32_t blk0 = (uint32_t)(BY * syi + r) * a.ux + sxi * BX;
-                lds_dma16_run<BX / 8, true>(reinterpret_cast<uint64_t>(base) + ((uint64_t)blk0 << 7), ve, ve ^ 64u, coef_lds + r * (BX * 128));
-            }
-            return;
+        const int16_t *base = a.coef + img * a.coef_stride;
+        if constexpr (INTHREAD) {
+            if (which) base = a.ccoef[which - 1] + img * a.ccoef_stride[which - 1];
         }
+        // BY runs of BX neighbouring blocks of the strip's block rows
+        const uint32_t ux = sgpr((uint32_t)a.ux);
+        const i32x4_t srd = rows_of(base, (uint32_t)(BY * syi), (uint32_t)min(BY, a.uy - BY * syi), ux);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int b = 8 * i + (lane >> 3);  // block within the strip: column b % BX, row b / BX
-            const int bx = sxi * BX + (b & (BX - 1)), by = BY * syi + (int)((unsigned)b / BX);
-            // blocks outside the plane fetch block 0; the store predicate discards their pixels
-            const uint32_t blk = (bx < a.ux && by < a.uy) ? (uint32_t)by * a.ux + bx : 0u;
-            const int c = (lane & 7) ^ ((b >> 1) & 7);
-            const char *g = reinterpret_cast<const char *>(base) + ((size_t)blk * 128 + 16 * c);
-            lds_dma16(g, coef_lds + 1024 * i);
-        }
+        for (int r = 0; r < BY; ++r)
+            lds_dma16_brun<BX / 8, true>(srd, ((uint32_t)r * ux + (uint32_t)(sxi * BX)) << 7, ve, ve ^ 64u, coef_lds + r * (BX * 128));
     };
 
     // 4:2:2, second chroma pass ((block, column) work-items): where the eight coefficients of this lane's column lie in the
@@ -557,44 +527,56 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         if constexpr (BX == 32) { sg0 = lane >= 48 ? 1 : 0; sg1 = 1; }
         else { sg0 = (int)((unsigned)lane / CPS); sg1 = (int)((64u + (unsigned)lane) / CPS); }
         const int j0 = lane - CPS * sg0, j1 = 64 + lane - CPS * sg1;
-        const uint32_t voff0 = sg0 * 8u * pitch + 16u * j0, voff1 = sg1 * 8u * pitch + 16u * j1;
-        const bool full = 8 * BY * syi + 8 * BY <= a.H && tile_px == BX * 8;   // wave-uniform
         const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
-        stores_behind_dma = (FAST && full) ? 16 : 0;
+        // The strip's rows through a BUFFER RESOURCE (round 5, as in k_quad420): base = the strip's first pixel, num_records = the
+        // bytes to the end of its last row INSIDE the image -- a row below the image is out of range and the hardware drops its
+        // store; a chunk right of the image gets an out-of-range voffset.  Two store instructions per pixel row, no predicate, no
+        // branch, the row is the scalar soffset.  FAST = false (any width): whole chunks the same way, the partial last chunk of
+        // a row (right-edge column only) dword- and byte-wise (store_tail).
+        const int rows_here = min(8 * BY, a.H - 8 * BY * syi);
+        const uint32_t strip_bytes = (uint32_t)rows_here * pitch;
+        const i32x4_t out_srd = make_srd(strip_out, strip_bytes);
+        const int rem0 = col0 ? nb - 16 * j0 : 0, rem1 = col1 ? nb - 16 * j1 : 0;   // bytes of the lane's chunks inside the image
+        const uint32_t base0 = sg0 * 8u * pitch + 16u * j0, base1 = sg1 * 8u * pitch + 16u * j1;
+        const uint32_t voff0 = (FAST ? col0 : rem0 >= 16) ? base0 : 0x80000000u;
+        const uint32_t voff1 = (FAST ? col1 : rem1 >= 16) ? base1 : 0x80000000u;
+        stores_behind_dma = FAST ? 16 : 0;
 
         // One pixel row of the strip's BY block rows at a time.  The row's LDS and memory traffic is software-
         // pipelined behind the NEXT row's arithmetic: row y is staged (ds_write) and read back as 16-byte chunks
         // (ds_read) right after its arithmetic, but the chunks are stored only after the arithmetic of row y + 1;
         // the chroma dwords of the next patch row are requested a row (SY == 1) or two (SY == 2) ahead.
         uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = make_uint4(0, 0, 0, 0);   // chunks of the previous pixel row
-        auto put = [&](uint8_t *o, const uint4 &v, int j) {
-            if constexpr (FAST) {
-                // streaming output, never re-read: non-temporal stores keep it from displacing
-                // the chroma planes in L2 / Infinity Cache (-6 % step time)
-                store_nt16(o, v);
-            } else {
-                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-                for (int k = 0; k < 16; ++k)
-                    if (16 * j + k < nb) o[k] = (uint8_t)(vv[k >> 2] >> (8 * (k & 3)));
-            }
+        auto store_tail = [&](const uint4 &v, uint32_t base, int rem, uint32_t soff) {   // the first `rem` (1 .. 15) bytes of a chunk
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(strip_out, 0, (int)strip_bytes, 0x00020000);
+            const bool part = rem > 0 && rem < 16;
+            const int nd = rem >> 2, nbytes = rem & 3;
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                __builtin_amdgcn_raw_buffer_store_b32(d[k], rsrc, (part && k < nd) ? base + 4u * k : 0x80000000u, soff, 0);
+            const uint32_t w = nd == 0 ? v.x : nd == 1 ? v.y : nd == 2 ? v.z : v.w;
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(w >> (8 * b)), rsrc, (part && b < nbytes) ? base + 4u * nd + b : 0x80000000u, soff, 0);
         };
         auto store_row = [&](int yy) {
-            uint8_t *rowp = strip_out + (size_t)yy * pitch;   // scalar
 #ifdef JA_X_NOSTORE  // experiment: everything but the global stores
             if (a.W < 0)
 #endif
-            if (FAST && full) {
-                // chunk `lane` from every lane, chunk 64 + lane from lanes 0 .. 31: scalar row base + 32-bit lane offset, and
-                // the second store under a narrowed EXEC instead of a branch (this path runs with all 64 lanes active)
+            {
                 const u32x4_t q0 = {pv0.x, pv0.y, pv0.z, pv0.w}, q1 = {pv1.x, pv1.y, pv1.z, pv1.w};
-                asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\t"
-                             "s_mov_b64 exec, %5\n\t"
-                             "global_store_dwordx4 %3, %4, %2 nt\n\t"
-                             "s_mov_b64 exec, -1"
-                             ::"v"(voff0), "v"(q0), "s"(rowp), "v"(voff1), "v"(q1), "s"(0xffffffffull) : "memory");
-            } else {
-                if (col0 && 8 * BY * syi + 8 * sg0 + yy < a.H) put(rowp + voff0, pv0, j0);
-                if (col1 && 8 * BY * syi + 8 * sg1 + yy < a.H) put(rowp + voff1, pv1, j1);
+                const uint32_t soff = (uint32_t)yy * pitch;   // scalar
+                asm volatile("buffer_store_dwordx4 %0, %1, %4, %5 offen nt\n\t"
+                             "buffer_store_dwordx4 %2, %3, %4, %5 offen nt\n\t"
+                             "s_nop 0"   // a store of more than 64 bits with an SGPR offset: one wait state before its data registers may be rewritten
+                             ::"v"(q0), "v"(voff0), "v"(q1), "v"(voff1), "s"(out_srd), "s"(soff) : "memory");
+                if constexpr (!FAST) {
+                    if (nb & 15) {   // wave-uniform: this strip column holds the image's right edge
+                        store_tail(pv0, base0, rem0, soff);
+                        store_tail(pv1, base1, rem1, soff);
+                    }
+                }
             }
         };
         // colour of pixel row y of the work-item's block from its luma samples and the row's chroma values; packed as 24 bytes

@@ -276,6 +276,40 @@ extension JPEG.Data.Spectral where Format == JPEG.Common
     }
 }
 
+extension JPEG.Data.Spectral
+{
+    /// `spectral.idct().interleaved(cosite:)` (decode.swift:4154-4165, 4182-4276) in ONE call, for ANY `JPEG.Format` -- what
+    /// `Rectangular.decompress(stream:cosite:)` runs behind the entropy decoder (decode.swift:4367-4374).  The coefficient planes
+    /// cross the link once, the samples once; formats whose planes lie at the image's scale or at half of it (factors 1 | 2)
+    /// take one launch with no Planar on the device, every other layout the staged kernels.  Same samples as the staged chain.
+    public
+    func rectangular(cosite cosited:Bool = false) -> JPEG.Data.Rectangular<Format>
+    {
+        var l:jpeg_amd_layout = AMD.layout(self.layout, size: self.size,
+            units: self.indices.map{ self[$0].units }, q: self.indices.map{ self[$0].q })
+        let tables:[UInt16] = AMD.tables(self)
+        let count:Int = self.size.x * self.size.y * self.count
+        var status:Int32 = 0
+        let values:[UInt16] = .init(unsafeUninitializedCapacity: count)
+        {
+            (buffer:inout UnsafeMutableBufferPointer<UInt16>, initialized:inout Int) in
+            status = AMD.withPointers(self.indices.map{ self[$0].buffer })
+            {
+                (planes:[UnsafePointer<Int16>?]) -> Int32 in
+                AMD.withContext
+                {
+                    jpeg_amd_host_spectral_rectangular($0, &l, planes, tables, .init(self.quanta.count),
+                        cosited ? 1 : 0, buffer.baseAddress)
+                }
+            }
+            if status != 0 { buffer.initialize(repeating: 0) }
+            initialized = count
+        }
+        AMD.check(status, "jpeg_amd_host_spectral_rectangular")
+        return .init(size: self.size, layout: self.layout, metadata: self.metadata, values: values)
+    }
+}
+
 extension JPEG.Data.Planar
 {
     public

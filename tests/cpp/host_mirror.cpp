@@ -96,6 +96,8 @@ int main(int argc, char **argv)
         const std::vector<uint8_t> staged = s.idct().interleaved(false).unpack(color::rgb);
         const std::vector<uint8_t> fused = s.decode(color::rgb);
         if (staged != fused) { std::cerr << "staged and fused decode differ\n"; return 1; }
+        // idct().interleaved() in one call (jpeg_amd_spectral_rectangular) == the staged chain
+        if (s.to_rectangular(false).unpack(color::rgb) != staged) { std::cerr << "to_rectangular() differs from idct().interleaved()\n"; return 1; }
         dump(std::string(argv[2]) + ".staged.rgb", staged);
         dump(std::string(argv[2]) + ".fused.rgb", fused);
         dump(std::string(argv[2]) + ".fused.ycc", s.decode(color::ycbcr));

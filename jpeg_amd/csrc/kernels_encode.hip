@@ -204,6 +204,9 @@ __device__ __forceinline__ void wave_store_blocks_halves(const uint32_t (&w)[32]
 #pragma unroll
             for (int c = 0; c < 8; ++c) mine[c ^ sw] = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
         }
+        // the lanes read what the other half of the wave has just written: reconverge first (the compiler may otherwise place the
+        // non-writers' reads in a branch of their own, ahead of the writers; k_generic_fused met exactly that)
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int producer = 32 * h + 8 * i + (lane >> 3);
@@ -215,6 +218,7 @@ __device__ __forceinline__ void wave_store_blocks_halves(const uint32_t (&w)[32]
 #endif
             if (blk != ~0u) store_nt16(base + ((size_t)blk << 7) + 16 * c, v);
         }
+        __builtin_amdgcn_wave_barrier();   // the other half's writes stay behind these reads
     }
 }
 
@@ -577,16 +581,13 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     const int need_x = chroma ? max(a.ux[0], sx * a.ux[1]) : a.ux[0];
     const int need_y = chroma ? max(a.uy[0], sy * a.uy[1]) : a.uy[0];
     a.tiles_x = (need_x + ETX - 1) / ETX;
-    // grey and 4:2:0 take the 8-row tiles (one luma block per work-item, four waves per SIMD): measured faster than the
-    // 16-row tiles at every size (tools/bench_encode.py, builds with -DJA_X_ENC_TY=16 / 8: 4096 x 4096 4:2:0 30.9 -> 28.8 us, 8192 x 8192
-    // 103.6 -> 97.5, 2048 x 2048 23.3 -> 15.4, grey 4096 x 4096 21.2 -> 16.9).  4:2:2 / 4:4:0 pool chroma per half tile and
-    // 4:4:4 parks it per lane: those keep 16 rows.
-#ifdef JA_X_ENC_TY8ALL   // experiment: 8-row tiles for every layout
-    const bool can8 = true;
-#else
-    const bool can8 = !chroma || (sx == 2 && sy == 2);
-#endif
-    const int ty = can8 && encode_ty_override() != 16 ? 8 : 16;
+    // Every layout takes 8-row tiles (one luma block per work-item; 99-124 VGPRs: four waves per SIMD, three for 4:4:4 whose
+    // parked chroma samples cost 32 KiB of LDS).  Grey and 4:2:0 since round 2 (4096 x 4096 4:2:0 30.9 -> 28.8 us, 2048 x 2048 23.3 ->
+    // 15.4); 4:2:2 / 4:4:0 / 4:4:4 since round 5 -- an 8-row tile of 4:2:2 / 4:4:0 holds exactly one chroma block per work-item, so the
+    // per-half chroma tiles of the 16-row kernels (two waves per SIMD, 151-183 VGPRs) are not needed: 8192 x 8192 4:2:2 112 -> 104 us,
+    // 4:4:4 155 -> 128, 4:4:0 118 -> 98; 4096 x 4096 33.3 -> 28.0, 40.2 -> 39.2, 32.5 -> 27.5 (profiles/r05_ab_encode_8_row_tiles.txt).
+    // The 16-row instantiations are built for the JA_X_ENC_TY experiment alone.
+    const int ty = encode_ty_override() == 16 ? 16 : 8;
     const int tiles_y = (need_y + ty - 1) / ty;
     if (a.tiles_x * tiles_y == 0 || n_images == 0) return hipSuccess;
     const dim3 grid(a.tiles_x * tiles_y, n_images);
@@ -596,37 +597,28 @@ hipError_t launch_fused_encode(hipStream_t stream, int n_images, const jpeg_amd_
     // (the vector-load path addresses a tile's rows with 32-bit byte offsets: 16 block rows x 8 x W x 3 B must stay below 2^32)
     const bool fast = (L.width & 7) == 0 && (pixel_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 7) == 0 &&
                       L.width <= (1 << 23);
-#define JA_E(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_>), grid, dim3(kThreads), 0, stream, a)
 #define JA_E8(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_, 8>), grid, dim3(kThreads), 0, stream, a)
 #define JA_E8I(SX_, SY_, RGB_, CH_, F_) hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_, 8, true>), grid, dim3(kThreads), 0, stream, a)
-    // (grey and 4:2:0 exist as 8-row tiles only: their 16-row instantiations -- 168 VGPRs with 8-14 of them spilled -- are
-    // built for the JA_X_ENC_TY experiment alone)
 #ifdef JA_X_ENC_TY
-#define JA_E16(SX_, SY_, RGB_, CH_, F_) JA_E(SX_, SY_, RGB_, CH_, F_)
+#define JA_ET(SX_, SY_, RGB_, CH_, F_) do { if (ty == 8) JA_E8(SX_, SY_, RGB_, CH_, F_); else hipLaunchKernelGGL((k_encode_fused<SX_, SY_, RGB_, CH_, F_>), grid, dim3(kThreads), 0, stream, a); } while (0)
 #else
-#define JA_E16(SX_, SY_, RGB_, CH_, F_) JA_E8(SX_, SY_, RGB_, CH_, F_)
+#define JA_ET(SX_, SY_, RGB_, CH_, F_) JA_E8(SX_, SY_, RGB_, CH_, F_)
 #endif
 #define JA_E2(RGB_, F_)                                         \
     do {                                                        \
-        if (!chroma && ty == 8) JA_E8(1, 1, RGB_, false, F_);   \
-        else if (!chroma) JA_E16(1, 1, RGB_, false, F_);        \
+        if (!chroma) JA_ET(1, 1, RGB_, false, F_);              \
         else if (sx == 2 && sy == 2 && ty == 8 && several_rounds) JA_E8I(2, 2, RGB_, true, F_); \
-        else if (sx == 2 && sy == 2 && ty == 8) JA_E8(2, 2, RGB_, true, F_); \
-        else if (sx == 2 && sy == 2) JA_E16(2, 2, RGB_, true, F_); \
-        else if (sx == 2 && sy == 1 && ty == 8) JA_E8(2, 1, RGB_, true, F_); \
-        else if (sx == 1 && sy == 2 && ty == 8) JA_E8(1, 2, RGB_, true, F_); \
-        else if (ty == 8) JA_E8(1, 1, RGB_, true, F_);          \
-        else if (sx == 2 && sy == 1) JA_E(2, 1, RGB_, true, F_); \
-        else if (sx == 1 && sy == 2) JA_E(1, 2, RGB_, true, F_); \
-        else JA_E(1, 1, RGB_, true, F_);                        \
+        else if (sx == 2 && sy == 2) JA_ET(2, 2, RGB_, true, F_); \
+        else if (sx == 2 && sy == 1) JA_ET(2, 1, RGB_, true, F_); \
+        else if (sx == 1 && sy == 2) JA_ET(1, 2, RGB_, true, F_); \
+        else JA_ET(1, 1, RGB_, true, F_);                       \
     } while (0)
     if (rgb) { if (fast) JA_E2(true, true); else JA_E2(true, false); }
     else     { if (fast) JA_E2(false, true); else JA_E2(false, false); }
 #undef JA_E2
-#undef JA_E16
+#undef JA_ET
 #undef JA_E8I
 #undef JA_E8
-#undef JA_E
     return hipGetLastError();
 }
 

@@ -27,6 +27,8 @@
 #include "dct.hpp"
 #include "kernels.hpp"
 
+#include <type_traits>
+
 namespace jpeg_amd {
 
 namespace {
@@ -54,6 +56,17 @@ struct GenArgs {
     int tiles_x;
 };
 
+// Float.rounded() (to nearest, ties away from zero: decode.swift:4264) of a NON-NEGATIVE float, exactly and without a select:
+// with r = trunc(v) the difference d = v - r is exact and lies in [0, 1), 2 d is exact, and trunc(2 d) is 1 exactly when d >= 1/2.
+// (roundf() compiles to a sequence around v_cndmask_b32, which issues ten times slower than anything else on gfx950 --
+// profiles/r05_probe_valu_classes.txt; the interpolated samples are sums of non-negative products, so v >= 0 always.)
+__device__ __forceinline__ float rounded_nonneg(float v)
+{
+    const float r = __builtin_truncf(v);
+    const float d = v - r;
+    return r + __builtin_truncf(d + d);
+}
+
 // truncating division by c = 1, 2 or 4 (log2c = 0, 1, 2) -- Int.quotientAndRemainder, decode.swift:4240
 __device__ __forceinline__ int div_trunc_pow2(int n, int c, int log2c)
 {
@@ -66,6 +79,7 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
     __shared__ __attribute__((aligned(16))) uint16_t tile[kGThreads * 64];   // at most one block per work-item: 32 KiB
     __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                             // modulated tables (natural order)
     __shared__ float tt[JPEG_AMD_MAX_PLANES][2][8];                           // t = clamp(Float(f) / Float(c)), f = -1 .. 6
+    __shared__ __attribute__((aligned(16))) uint32_t ostage[kGThreads / 64][4 * 64 * COUNT];   // per wave: 4 rows x 128 px x COUNT samples
 
     const int t = threadIdx.x, img = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
@@ -144,10 +158,10 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
         const int y = y0 + 32 * pass + (t >> 3);
         int xb = x0 + 16 * (t & 7);
         asm volatile("" : "+v"(xb));   // opaque per pass: what depends only on x would otherwise be hoisted out of the pass loop (~190 VGPRs)
-        if (y >= a.H || xb >= a.W) continue;
         uint32_t o[8 * COUNT];   // 16 pixels x COUNT samples, packed in pairs in the output's order
 #pragma unroll
         for (int i = 0; i < 8 * COUNT; ++i) o[i] = 0;
+        if (y < a.H && xb < a.W)    // (a work-item without pixels still takes part in the wave's stores below)
 #pragma unroll
         for (int p = 0; p < COUNT; ++p) {
             __builtin_amdgcn_sched_barrier(0);   // one plane at a time: left alone, the scheduler issues every plane's LDS reads up front
@@ -171,6 +185,45 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                 const int jy = min(iy + 1, ph - 1);
                 const float ty = tt[p][1][fy + 1];
                 const uint16_t *r0 = pt + (iy - oy) * pitch, *r1 = pt + (jy - oy) * pitch;
+                // The horizontal positions of 16 consecutive pixels starting at a multiple of 16 are known at compile time up
+                // to the plane's edge clamps: away from the edges the two sample rows are fetched ONCE as whole dwords (the 9 - 17
+                // samples the 16 pixels share) and every pixel picks its two by constant index -- the same float operations
+                // on the same values as the per-pixel form below (decode.swift:4240-4264), which the threads at the plane's
+                // left / right edge keep.  kind: 0 a factor-2 axis, centred (a, b, c = -1, 2, 4: i = (2 x - 1) / 4, f = 3 | 1);
+                // 1 a factor-2 axis, cosited (0, 1, 2: i = x / 2, f = x & 1); 2 the axis is at the image's scale (i = x, f = 0).
+                const int kind = P.rx == 1 ? 2 : (P.cx == 4 ? 0 : 1);
+                const int seg = t & 7;
+                const bool away = kind == 2 || ((kind == 1 || xb >= 16) && (xb >> 1) + 8 <= pw - 1);
+                if (away) {
+                    auto pixels = [&](auto K) {
+                        constexpr int KIND = decltype(K)::value;
+                        constexpr int ND = KIND == 0 ? 6 : KIND == 1 ? 5 : 8;            // dwords per row
+                        const int w0 = KIND == 0 ? 8 * seg + 6 : KIND == 1 ? 8 * seg + 8 : 16 * seg;   // first tile column fetched (even)
+                        float u0[2 * ND], u1[2 * ND];
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) {
+                            const uint32_t a0 = *reinterpret_cast<const uint32_t *>(r0 + w0 + 2 * d);
+                            const uint32_t a1 = *reinterpret_cast<const uint32_t *>(r1 + w0 + 2 * d);
+                            u0[2 * d] = (float)(a0 & 0xffffu); u0[2 * d + 1] = (float)(a0 >> 16);
+                            u1[2 * d] = (float)(a1 & 0xffffu); u1[2 * d + 1] = (float)(a1 >> 16);
+                        }
+                        // t of even / odd pixels: Float(f) / Float(c), f = 3 | 1 (centred), 0 | 1 (cosited), 0 (full scale)
+                        const float te = tt[p][0][(KIND == 0 ? 3 : 0) + 1], to = tt[p][0][(KIND == 2 ? 0 : 1) + 1];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            // index of sample i_x in the fetched window: centred floor((2 i - 1) / 4) + 2, cosited i / 2, full scale i
+                            const int ia = KIND == 0 ? (i == 0 ? 1 : (2 * i - 1) / 4 + 2) : KIND == 1 ? i / 2 : i;
+                            const int ib = KIND == 2 ? (i < 15 ? i + 1 : 15) : ia + 1;      // (full scale: the neighbour weighs 0)
+                            const float tx = (i & 1) ? to : te;
+                            const float v0 = u0[ia] * (1.0f - tx) + u0[ib] * tx;           // decode.swift:4260-4261
+                            const float v1 = u1[ia] * (1.0f - tx) + u1[ib] * tx;
+                            s[i] = (uint32_t)rounded_nonneg(v0 * (1.0f - ty) + v1 * ty);  // :4264
+                        }
+                    };
+                    if (kind == 0) pixels(std::integral_constant<int, 0>{});
+                    else if (kind == 1) pixels(std::integral_constant<int, 1>{});
+                    else pixels(std::integral_constant<int, 2>{});
+                } else
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int x = xb + i;
@@ -185,7 +238,7 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                     const float u10 = (float)r1[lix], u11 = (float)r1[ljx];
                     const float v0 = u00 * (1.0f - tx) + u01 * tx;   // decode.swift:4260-4261
                     const float v1 = u10 * (1.0f - tx) + u11 * tx;
-                    s[i] = (uint32_t)round_half_away(v0 * (1.0f - ty) + v1 * ty);   // :4264
+                    s[i] = (uint32_t)rounded_nonneg(v0 * (1.0f - ty) + v1 * ty);   // :4264
                 }
             }
 #pragma unroll
@@ -194,14 +247,41 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                 o[e >> 1] |= (s[i] & 0xffffu) << (16 * (e & 1));
             }
         }
-        uint16_t *dst = a.out + img * a.out_stride + ((size_t)y * a.W + xb) * COUNT;
-        if (xb + 16 <= a.W) {
+        // ---- out through a wave-private LDS staging buffer.  A work-item holds 32 COUNT contiguous bytes; storing them itself would
+        //      touch 64 different 128-byte lines per instruction, 16 bytes each (partial-line writes: what k_encode_fused once spent a
+        //      third of its time on).  Instead the wave's 8 rows x 128 pixels go to LDS four rows at a time and come back
+        //      lane-linear: every store instruction writes 64 consecutive 16-byte chunks of whole row segments. ----
+        const int wv = t >> 6, lane = t & 63;
+        uint32_t *st = ostage[wv];
+        const int nvalid = min(GTW, a.W - x0) * COUNT;          // samples of a tile row inside the image
 #pragma unroll
-            for (int k = 0; k < 2 * COUNT; ++k)   // (rows need not be 16-byte aligned: the hardware takes unaligned dwordx4 stores)
-                *reinterpret_cast<uint4 *>(dst + 8 * k) = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-        } else {
-            const int n = (a.W - xb) * COUNT;
-            for (int e = 0; e < n; ++e) dst[e] = (uint16_t)(o[e >> 1] >> (16 * (e & 1)));
+        for (int h = 0; h < 2; ++h) {
+            if ((((t >> 3) & 4) >> 2) == h) {
+                uint4 *mine = reinterpret_cast<uint4 *>(st + ((t >> 3) & 3) * (64 * COUNT) + (t & 7) * (8 * COUNT));
+#pragma unroll
+                for (int k = 0; k < 2 * COUNT; ++k) mine[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+            }
+            // The lanes read what OTHER lanes of the wave have just written: the wave must reconverge first -- left alone, the
+            // compiler duplicates the reads into the branch of the lanes that did not write, and that branch may run before the
+            // writers' (seen: the first 32 chunks of every second group of four rows were stale).  The LDS itself executes one
+            // wave's operations in order.
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < COUNT; ++k) {          // 4 rows x 16 COUNT chunks = 64 COUNT chunks, lane-linear
+                const int g = 64 * k + lane, row = g / (16 * COUNT), cc = g - row * (16 * COUNT);
+                const uint4 v = *reinterpret_cast<const uint4 *>(st + 4 * g);
+                const int yy = y0 + 32 * pass + 8 * wv + 4 * h + row;
+                if (yy < a.H && 8 * cc < nvalid) {
+                    uint16_t *dst = a.out + img * a.out_stride + ((size_t)yy * a.W + x0) * COUNT + 8 * cc;
+                    if (8 * cc + 8 <= nvalid) {
+                        *reinterpret_cast<uint4 *>(dst) = v;      // (rows need not be 16-byte aligned: the hardware takes unaligned dwordx4 stores)
+                    } else {
+                        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                        for (int e = 0; e < nvalid - 8 * cc; ++e) dst[e] = (uint16_t)(d[e >> 1] >> (16 * (e & 1)));
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // ... and the next group's writes stay behind these reads
         }
     }
 }

@@ -184,21 +184,23 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
             const uint32_t ve = lane_chunk(lane);
             const char *base_b = reinterpret_cast<const char *>(a.coef[1] + img * a.coef_stride[1]);
             const char *base_r = reinterpret_cast<const char *>(a.coef[2] + img * a.coef_stride[2]);
+            const i32x4_t srd_b = make_srd(base_b, plane_bytes), srd_r = make_srd(base_r, plane_bytes);
             if constexpr (BX == 32) {   // four runs of sixteen blocks
-                const i32x4_t srd_b = make_srd(base_b, plane_bytes), srd_r = make_srd(base_r, plane_bytes);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int row = role < 2 ? top + 2 * role + (u >> 1) : ((u >> 1) ? CBR * (top + QS) : CBR * top - 1);
                     lds_dma16_brun<2, false>((u & 1) ? srd_r : srd_b, chroma_off(row, CBW * sxi), ve, ve ^ 64u, coef_lds + 2048 * u);
                 }
-            } else {                    // pieces of eight blocks: role 0, 1 eight of them (a block row each), role 2 four
+            } else if (role < 2) {      // eight pieces of eight blocks, a block row each: plane (i >> 1) & 1
 #pragma unroll
-                for (int i = 0; i < NDMA_C; ++i) {
-                    if (role == 2 && 8 * i >= NHROW) break;
-                    const int pl = role < 2 ? (i >> 1) & 1 : i & 1;   // (scalar)
-                    const int row = role < 2 ? CBR * (top + 2 * role + (i >> 2)) + (i & 1) : ((i >> 1) ? CBR * (top + QS) : CBR * top - 1);
-                    lds_dma16_brun<1, false>(make_srd(pl ? base_r : base_b, plane_bytes), chroma_off(row, CBW * sxi), (i & 1) ? ve ^ 64u : ve, 0u, coef_lds + 1024 * i);
-                }
+                for (int i = 0; i < NDMA_C; ++i)
+                    lds_dma16_brun<1, false>(((i >> 1) & 1) ? srd_r : srd_b, chroma_off(CBR * (top + 2 * role + (i >> 2)) + (i & 1), CBW * sxi),
+                                             (i & 1) ? ve ^ 64u : ve, 0u, coef_lds + 1024 * i);
+            } else {                    // role 2: four pieces -- above / below (i >> 1), plane i & 1
+#pragma unroll
+                for (int i = 0; i < NHROW / 8; ++i)
+                    lds_dma16_brun<1, false>((i & 1) ? srd_r : srd_b, chroma_off((i >> 1) ? CBR * (top + QS) : CBR * top - 1, CBW * sxi),
+                                             (i & 1) ? ve ^ 64u : ve, 0u, coef_lds + 1024 * i);
             }
             return;
         }

@@ -198,22 +198,35 @@ __device__ __forceinline__ void idct_pass2_row(const float (&f)[64], int y, floa
     idct8<true>(r, level, g);
 }
 
-// ONE output row of idct_block: row 0 (last == false) or row 7 (last == true; may differ per lane).
+// x with its sign flipped where `flip` is 0x80000000 (else 0): r0 + flip_sign(s0, ...) is idct8's output 0 (r0 + s0) or 7
+// (r0 - s0 == r0 + (-s0), the same IEEE operation) chosen PER LANE without a select -- v_cndmask_b32 issues ten times slower
+// than a v_xor_b32 on gfx950 (profiles/r05_probe_valu_classes.txt).
+__device__ __forceinline__ float flip_sign(float x, uint32_t flip)
+{
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) ^ flip);
+}
+
+// ONE output row of idct_block: row 0 (flip == 0) or row 7 (flip == 0x80000000; may differ per lane).
 // Same operations in the same order for the values that are kept; what the other rows would have
-// needed is never computed (the unused butterfly outputs are dead code).
+// needed is never computed: of the first pass only idct8's r0 = (h0 + h4) + (h2 + h6) and s0 = (h1 + h7) + (h5 + h3).
 template <typename QPtr>
-__device__ __forceinline__ void idct_block_edge_row(const uint32_t (&w)[32], QPtr q, float level, bool last,
+__device__ __forceinline__ void idct_block_edge_row(const uint32_t (&w)[32], QPtr q, float level, uint32_t flip,
                                                     float (&g)[8])
 {
     float t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        float h[8], res[8];
+        float h[8];
 #pragma unroll
         for (int hh = 0; hh < 8; ++hh)
             h[hh] = q[8 * hh + k] * coef_as_float(w, zigzag_of(k, hh));
-        idct8<false>(h, 0.0f, res);
-        t[k] = last ? res[7] : res[0];
+        const float a0 = h[0] + h[4];          // idct8<false>: e = h0
+        const float b  = h[2] + h[6];
+        const float r0 = a0 + b;
+        const float d1 = h[1] + h[7];
+        const float d3 = h[5] + h[3];
+        const float s0 = d1 + d3;
+        t[k] = r0 + flip_sign(s0, flip);       // res[0] = r0 + s0, res[7] = r0 - s0
     }
     idct8<true>(t, level, g);
 }
@@ -246,6 +259,35 @@ __device__ __forceinline__ void idct_block_edge_cols(const uint32_t (&w)[32], QP
         const float s0 = d1 + d3;
         c0[y] = r0 + s0;
         c7[y] = r0 - s0;
+    }
+}
+
+// ONE edge column of idct_block, chosen per lane: column 0 (flip == 0) or column 7 (flip == 0x80000000) -- idct_block_edge_cols
+// with the final r0 +- s0 folded into one addition (flip_sign above).
+template <typename QPtr>
+__device__ __forceinline__ void idct_block_edge_col(const uint32_t (&w)[32], QPtr q, float level, uint32_t flip, float (&c)[8])
+{
+    float f[64];  // f[8*k + y]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float h[8], res[8];
+#pragma unroll
+        for (int hh = 0; hh < 8; ++hh)
+            h[hh] = q[8 * hh + k] * coef_as_float(w, zigzag_of(k, hh));
+        idct8<false>(h, 0.0f, res);
+#pragma unroll
+        for (int y = 0; y < 8; ++y) f[8 * k + y] = res[y];
+    }
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const float e  = level + f[8 * 0 + y];
+        const float a0 = e + f[8 * 4 + y];
+        const float b  = f[8 * 2 + y] + f[8 * 6 + y];
+        const float r0 = a0 + b;
+        const float d1 = f[8 * 1 + y] + f[8 * 7 + y];
+        const float d3 = f[8 * 5 + y] + f[8 * 3 + y];
+        const float s0 = d1 + d3;
+        c[y] = r0 + flip_sign(s0, flip);
     }
 }
 

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 const bool below = lane >= 32;
                 const int pl = (lane >> 4) & 1, c = lane & 15;
                 float r8[8];
-                idct_block_edge_row(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, !below, r8);
+                idct_block_edge_row(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, (uint32_t)(lane - 32) & 0x80000000u, r8);   // above (lane < 32): the last row
                 uint32_t p01[2];
                 trunc_pack8(r8, p01);
                 if (below ? 2 * syi + 2 < uyc : syi > 0) {
@@ -524,10 +524,12 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         const uint32_t pitch = 3u * a.W;
         uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(8 * BY * syi) * a.W + BX * 8 * sxi) * 3;
         int sg0, sg1;   // segments of chunk `lane` and of chunk 64 + lane (the latter for lanes 0..31)
-        if constexpr (BX == 32) { sg0 = lane >= 48 ? 1 : 0; sg1 = 1; }
+        if constexpr (BX == 32) { sg0 = 1 + ((lane - 48) >> 31); sg1 = 1; asm volatile("" : "+v"(sg0)); }   // (lane >= 48 ? 1 : 0, without a select)
         else { sg0 = (int)((unsigned)lane / CPS); sg1 = (int)((64u + (unsigned)lane) / CPS); }
         const int j0 = lane - CPS * sg0, j1 = 64 + lane - CPS * sg1;
-        const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
+        // inside the image: 16 j < nb (and lane < 32 for the second chunk) as the SIGN of a difference (kernels_quad.hip: no v_cndmask_b32)
+        const int in0 = 16 * j0 - nb, in1 = max(16 * j1 - nb, lane - 32);            // negative: inside
+        const bool col0 = in0 < 0, col1 = in1 < 0;
         // The strip's rows through a BUFFER RESOURCE (round 5, as in k_quad420): base = the strip's first pixel, num_records = the
         // bytes to the end of its last row INSIDE the image -- a row below the image is out of range and the hardware drops its
         // store; a chunk right of the image gets an out-of-range voffset.  Two store instructions per pixel row, no predicate, no
@@ -538,8 +540,11 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         const i32x4_t out_srd = make_srd(strip_out, strip_bytes);
         const int rem0 = col0 ? nb - 16 * j0 : 0, rem1 = col1 ? nb - 16 * j1 : 0;   // bytes of the lane's chunks inside the image
         const uint32_t base0 = sg0 * 8u * pitch + 16u * j0, base1 = sg1 * 8u * pitch + 16u * j1;
-        const uint32_t voff0 = (FAST ? col0 : rem0 >= 16) ? base0 : 0x80000000u;
-        const uint32_t voff1 = (FAST ? col1 : rem1 >= 16) ? base1 : 0x80000000u;
+        auto place = [](uint32_t base, int d) -> uint32_t {      // base where d < 0, an out-of-range voffset elsewhere: one v_bfi_b32
+            const uint32_t m = (uint32_t)(d >> 31);
+            return (base & m) | (0x80000000u & ~m);
+        };
+        const uint32_t voff0 = place(base0, FAST ? in0 : in0 + 15), voff1 = place(base1, FAST ? in1 : max(16 * j1 - nb + 15, lane - 32));
         stores_behind_dma = FAST ? 16 : 0;
 
         // One pixel row of the strip's BY block rows at a time.  The row's LDS and memory traffic is software-

@@ -142,7 +142,11 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
         sxi = (int)col + a.sx0;
     };
     const int strips_y = (a.uy + BY - 1) / BY;
+#ifdef JA_X_ROLEROT   // experiment: every wave takes every role once in four trips (instead of swapping between the wave pairs)
+    auto role_of = [&](int t) -> int { return (qp + t) & 3; };
+#else
     auto role_of = [&](int t) -> int { return (qp + 2 * (t & 1)) & 3; };
+#endif
 
     // LDS-DMA of a pass's blocks: an instruction moves 64 x 16 B; slot u = 64 i + lane of the wave's buffer holds chunk
     // (u & 7) ^ ((b >> 1) & 7) of block b = u >> 3 -- the XOR on the SOURCE address makes the later per-work-item ds_read_b128
@@ -338,26 +342,27 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
             } else if (role == 2) {   // above: the block's last sample row; below: its first
                 const bool below = lane >= 2 * CBW;
                 float r[8];
-                idct_block_edge_row(w, TransposedTable{sqw[qp][1 + pl]}, 128.5f, !below, r);
+                // above the stack: the block's LAST sample row (sign flip of idct8's s0), below it: the first -- from the lane's
+                // place, arithmetically: (lane - 2 CBW) is negative exactly for the lanes above
+                idct_block_edge_row(w, TransposedTable{sqw[qp][1 + pl]}, 128.5f, (uint32_t)(lane - 2 * CBW) & 0x80000000u, r);
                 uint32_t p01[2];
                 trunc_pack8(r, p01);
                 const uint32_t p0 = p01[0], p1 = p01[1];
                 JA_PHASE(2)
                 lds_wait_ge_seen(done, (uint32_t)(QS * trip), done_seen);
                 JA_PHASE(3)
-                if (lane < NHROW && (below ? stack_below : stack_above)) {
+                // (the lanes of the rows that exist, as a scalar range: no per-lane select of the two flags)
+                const int lo = stack_above ? 0 : 2 * CBW, hi = stack_below ? NHROW : 2 * CBW;
+                if (lane >= lo && lane < hi) {
                     uint32_t *dst = tile + (below ? QROWS - 1 : 0) * PITCH + 1 + 2 * (lane % CBW);
                     dst[0] = p0; dst[1] = p1;
                 }
             } else {   // neighbour blocks: the column that touches the stack (first of the right, last of the left neighbour)
                 const int rowi = lane >> 2, side = lane & 1;
-                float c0[8], c7[8];
-                idct_block_edge_cols(w, TransposedTable{sqw[qp][1 + pl]}, 128.5f, c0, c7);
-                uint32_t e[8];   // the edge sample of each row, replicated
+                uint32_t e[8];   // the edge sample of each row, replicated: column 0 of the right neighbour (side 1), column 7 of the left one
                 {
                     float edge[8];
-#pragma unroll
-                    for (int y = 0; y < 8; ++y) edge[y] = side ? c0[y] : c7[y];
+                    idct_block_edge_col(w, TransposedTable{sqw[qp][1 + pl]}, 128.5f, side ? 0u : 0x80000000u, edge);
                     trunc_bytes8(edge, e);
 #pragma unroll
                     for (int y = 0; y < 8; ++y) e[y] *= 0x01010101u;
@@ -367,7 +372,8 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
                 JA_PHASE(2)
                 lds_wait_ge_seen(done, (uint32_t)(QS * trip), done_seen);
                 JA_PHASE(3)
-                if (lane < NSIDE && (side ? has_right : has_left)) {
+                const uint32_t sides = (has_left ? 1u : 0u) | (has_right ? 2u : 0u);   // scalar; bit `side` of it, per lane
+                if (lane < NSIDE && ((sides >> side) & 1u)) {
                     uint32_t *col = tile + (side ? PITCH - 1 : 0);
                     if (rowi == 0) { if (stack_above) col[0] = e[7]; }                                  // corner samples
                     else if (rowi == QS * CBR + 1) { if (stack_below) col[(QROWS - 1) * PITCH] = e[0]; }
@@ -503,10 +509,13 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
         const uint32_t pitch = 3u * a.W;
         uint8_t *strip_out = a.out + img * a.out_stride + ((size_t)(8 * BY * syi) * a.W + BX * 8 * sxi) * 3;
         int sg0, sg1;   // segments of chunk `lane` and of chunk 64 + lane (the latter for lanes 0..31)
-        if constexpr (BX == 32) { sg0 = lane >= 48 ? 1 : 0; sg1 = 1; }
+        if constexpr (BX == 32) { sg0 = 1 + ((lane - 48) >> 31); sg1 = 1; }   // (lane >= 48 ? 1 : 0, without a select)
         else { sg0 = (int)((unsigned)lane / CPS); sg1 = (int)((64u + (unsigned)lane) / CPS); }
         const int j0 = lane - CPS * sg0, j1 = 64 + lane - CPS * sg1;
-        const bool col0 = 16 * j0 < nb, col1 = lane < 32 && 16 * j1 < nb;
+        // inside the image: 16 j < nb (and, for the second chunk, lane < 32) -- as the SIGN of a difference, so that what depends on it
+        // is formed with shifts and v_bfi instead of v_cndmask_b32 (ten times slower than either on gfx950)
+        const int in0 = 16 * j0 - nb, in1 = max(16 * j1 - nb, lane - 32);            // negative: inside
+        const bool col0 = in0 < 0, col1 = in1 < 0;
         // FAST: the strip's rows through a BUFFER RESOURCE (round 5).  base = the strip's first pixel, num_records = the bytes from
         // there to the end of the strip's last row INSIDE the image: a row below the image is out of range and the hardware drops
         // its store (range check: voffset >= num_records - soffset, tools/probe_buffer.hip); a chunk right of the image gets a
@@ -521,8 +530,13 @@ __global__ __launch_bounds__(kThreads, JA_QUAD_WAVES) void k_quad420(QuadArgs a)
         // of its row segment (1 .. 15 bytes), which goes dword- and byte-wise (store_tail below).
         const int rem0 = col0 ? nb - 16 * j0 : 0, rem1 = col1 ? nb - 16 * j1 : 0;   // bytes of the lane's chunks inside the image
         const uint32_t base0 = sg0 * 8u * pitch + 16u * j0, base1 = sg1 * 8u * pitch + 16u * j1;
-        const uint32_t voff0 = (FAST ? col0 : rem0 >= 16) ? base0 : 0x80000000u;
-        const uint32_t voff1 = (FAST ? col1 : rem1 >= 16) ? base1 : 0x80000000u;
+        // voffset = the chunk's place, or an out-of-range value: base where d < 0, 0x80000000 elsewhere (d: FAST in0 / in1; else "fewer than
+        // 16 bytes of the chunk are inside")
+        auto place = [](uint32_t base, int d) -> uint32_t {
+            const uint32_t m = (uint32_t)(d >> 31);               // all ones where d < 0
+            return (base & m) | (0x80000000u & ~m);               // one v_bfi_b32
+        };
+        const uint32_t voff0 = place(base0, FAST ? in0 : in0 + 15), voff1 = place(base1, FAST ? in1 : max(16 * j1 - nb + 15, lane - 32));
         stores_behind_dma = FAST ? 16 : 0;
         JA_PHASE(7)
 

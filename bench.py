@@ -261,6 +261,13 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def under_profiler() -> bool:
+    """True when this process itself runs under rocprofv3 (tools/profile_round.sh): a nested profiler run would be an exec of a
+    launcher from a process whose preloaded tool library has already initialised the GPU, which the GPU boxes refuse."""
+    return any(k in os.environ for k in ("ROCPROFILER_LIBRARY_CTOR", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or \
+        "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
 def measure_traffic_live(timeout=240):
     """HBM bytes per launch of the C3 step's kernel, measured NOW on this GPU: two child runs of tools/run_c3.py (the same
     jpeg_amd_decode_batch call on the same 8192 x 8192 workload) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
@@ -271,6 +278,8 @@ def measure_traffic_live(timeout=240):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if under_profiler():
+        return None, "this run is itself being profiled"
     if os.environ.get("JPEG_AMD_LIBRARY"):
         return None, "JPEG_AMD_LIBRARY is set: the timed library is not the product build"
     out = {}
@@ -304,6 +313,8 @@ def measure_valu_live(which):
     rocprofv3 child runs of the same call on the same workload, turned into VALU issue cycles needed per SIMD / cycles elapsed."""
     try:
         from tools import valu_roofline as vr
+        if under_profiler():
+            return {"error": "this run is itself being profiled"}
         if os.environ.get("JPEG_AMD_LIBRARY"):
             return {"error": "JPEG_AMD_LIBRARY is set: the timed library is not the product build"}
         lib = os.path.join(ROOT, "jpeg_amd", "libjpeg_amd.so")

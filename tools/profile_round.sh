@@ -23,8 +23,8 @@ run_cfg() {
   cp $O/$cfg/pw/pw_counter_collection.csv $O/$cfg/pmc_write_size.csv
   rm -rf $O/$cfg/kt $O/$cfg/pf $O/$cfg/pw
 }
-run_cfg c3 $R/bench.py --workload c3 --steps 50 --warmup 10 --no-extras --no-cpu --traffic none --no-c5-job --no-parity
-run_cfg c5 $R/bench.py --workload c5 --steps 5 --warmup 2 --no-extras --no-cpu --traffic none --no-parity
+run_cfg c3 $R/bench.py --workload c3 --steps 50 --warmup 10 --no-extras --no-cpu --traffic none --valu none --no-c5-job --no-parity
+run_cfg c5 $R/bench.py --workload c5 --steps 5 --warmup 2 --no-extras --no-cpu --traffic none --valu none --no-parity
 run_cfg c2 $R/tools/bench_idct.py --units 2048 --only-main
 run_cfg c4 $R/tools/bench_encode.py --only 4:2:0
 cd $R

@@ -282,6 +282,11 @@ def test_host_buffer_abi(J, ctx):
                                               _lib.COLOR_YCC8, ycc.ctypes.data)
     assert st == 0
     assert G.sha(ycc) == G.entry("color-sequential-1.jpg")["gold"]["ycc_sha256"]
+    # idct().interleaved() in one call with host buffers (what Spectral.rectangular(cosite:) of the shim binds)
+    rect2 = np.empty((img.height, img.width, 3), np.uint16)
+    st = lib.jpeg_amd_host_spectral_rectangular(ctx.handle, C.byref(L), _lib.ptr_array([c.ctypes.data for c in coef]),
+                                                q.ctypes.data, 3, 0, rect2.ctypes.data)
+    assert st == 0 and (rect2 == rect).all()
 
     # encode side
     rgb, esize = G.encode_source()

@@ -19,6 +19,13 @@
 #include <thread>
 #include <vector>
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#define JA_X86_STREAMING 1
+#else
+#define JA_X86_STREAMING 0
+#endif
+
 #include "../../include/jpeg_amd.h"
 
 namespace {
@@ -31,9 +38,6 @@ struct Huffman {
     int32_t valptr[17];
     int32_t mincode[17];
     uint8_t symbols[256];
-    // AC shortcut: when code + magnitude bits of a coefficient fit in the 9-bit window, one lookup
-    // yields the value: (value << 8) | (run << 4) | total bits; 0 = take the general path
-    int16_t fast_ac[512];
     // Sequential scans (round 5): ONE lookup per symbol on a 10-bit window wherever code + magnitude bits fit in it.
     //   look_ac: bits 0-4 bits to skip (0 = take the general path), bits 5-9 coefficients to advance (run + 1; 16 for ZRL;
     //            0 = EOB), bit 10 a coefficient is stored, bits 16-31 its value.
@@ -91,16 +95,6 @@ struct Huffman {
             code <<= 1;
         }
         maxcode[17] = 0x7fffffff;
-        for (int i = 0; i < 512; ++i) {
-            fast_ac[i] = 0;
-            const uint16_t f = fast[i];
-            if (!f) continue;
-            const int len = f >> 8, rs = f & 0xff, run = rs >> 4, size = rs & 15;
-            if (size == 0 || len + size > 9) continue;
-            int v = (i >> (9 - len - size)) & ((1 << size) - 1);      // the magnitude bits that follow the code
-            if (v < (1 << (size - 1))) v += 1 - (1 << size);          // T.81 F.2.2.1 extension
-            if (v >= -128 && v <= 127) fast_ac[i] = (int16_t)(v * 256 + run * 16 + len + size);
-        }
         for (int w = 0; w < 1024; ++w) {
             int len;
             const int sym = lookup((uint16_t)(w << 6), len);
@@ -194,6 +188,138 @@ struct BitReader {
         hit_marker = false;
     }
 };
+
+// ---- sequential scans: the fast path (round 5) -------------------------------------------------------------------------
+// The entropy-coded bytes of one restart interval are first copied WITHOUT their stuffing (0xFF 0x00 -> 0xFF; the copy ends
+// at the first marker) and followed by 16 bytes of 0xFF, so that the reader below needs no test for stuffing, markers or the
+// end of the data: past the end it reads 1-bits, exactly what BitReader supplies there.
+struct CleanReader {
+    const uint8_t *p, *limit;   // limit: the last address a load may start at (all 0xFF from there on)
+    uint64_t acc = 0;           // left-aligned; the bits below the valid ones are already those of the bytes that follow
+    int nbits = 0;
+
+    inline void refill()        // to >= 56 valid bits, without a branch
+    {
+        uint64_t x;
+        std::memcpy(&x, p, 8);
+        acc |= __builtin_bswap64(x) >> nbits;
+        p += (63 - nbits) >> 3;
+        nbits |= 56;
+        p = p > limit ? limit : p;
+    }
+    inline uint32_t peek10() const { return (uint32_t)(acc >> 54); }
+    inline void skip(int n) { acc <<= n; nbits -= n; }
+    inline int symbol(const Huffman &h)                          // any code (<= 16 bits): call with >= 16 valid bits
+    {
+        int len;
+        const int sym = h.lookup((uint16_t)(acc >> 48), len);
+        skip(len);
+        return sym;
+    }
+    inline int magnitude(int size)                               // 1 <= size <= 16 bits, extended (T.81 F.2.2.1)
+    {
+        const int v = (int)(acc >> (64 - size));
+        skip(size);
+        return v >= (1 << (size - 1)) ? v : v - (1 << size) + 1;
+    }
+};
+
+// Removes the stuffing of [b, e) into `out` (grown as needed); returns the end of the clean bytes, which 16 bytes of 0xFF follow.
+inline const uint8_t *unstuff(const uint8_t *b, const uint8_t *e, std::vector<uint8_t> &out)
+{
+    if (out.size() < (size_t)(e - b) + 16) out.resize((size_t)(e - b) + 16);
+    uint8_t *o = out.data();
+    while (b < e) {
+        const uint8_t *ff = static_cast<const uint8_t *>(std::memchr(b, 0xff, (size_t)(e - b)));
+        if (!ff) { std::memcpy(o, b, (size_t)(e - b)); o += e - b; break; }
+        if (ff + 1 < e && ff[1] == 0x00) {                       // a stuffed 0xFF: data
+            std::memcpy(o, b, (size_t)(ff + 1 - b));
+            o += ff + 1 - b;
+            b = ff + 2;
+        } else {                                                 // RSTn, another marker, or a lone 0xFF at the end: stop
+            std::memcpy(o, b, (size_t)(ff - b));
+            o += ff - b;
+            break;
+        }
+    }
+    std::memset(o, 0xff, 16);
+    return o;
+}
+
+// A finished block goes to its plane whole.  With `streaming` (16-byte aligned planes) by non-temporal stores: the plane is
+// written once and read next by a DMA engine or another thread, so the lines need not be fetched, nor kept, by this core.
+inline void store_block(int16_t *dst, const int16_t *tmp, bool streaming)
+{
+#if JA_X86_STREAMING
+    if (streaming) {
+        const __m128i *s = reinterpret_cast<const __m128i *>(tmp);
+        __m128i *d = reinterpret_cast<__m128i *>(dst);
+        for (int i = 0; i < 8; ++i) _mm_stream_si128(d + i, _mm_load_si128(s + i));
+        return;
+    }
+#endif
+    (void)streaming;
+    std::memcpy(dst, tmp, 128);
+}
+
+// Several AC symbols per lookup: the table over a kChainBits window, composed from Huffman::look_ac, holds as many whole
+// symbols as fit in the window and store at most two coefficients -- "3 -1 ZRL ZRL ZRL EOB" is one entry (the reference's
+// encoder, and this library's, emit a ZRL for every complete run of 16 zeros, also in front of the EOB: encode.swift:917-958).
+//   bits 0-3 bits to skip (0: the first symbol does not fit, take the general path), 4-10 / 11-17 offsets from k of the two
+//   stores, 18-24 advance of k, bit 25 the block ends here (EOB), 26-31 the advance in front of the LAST symbol,
+//   32-47 / 48-63 the two values.
+// An entry always stores twice: one with a single coefficient stores it twice, one with none stores 0 at k, which is still 0
+// in a block that is filled front to back.  It may only be used while k + (advance in front of the last symbol) <= 63: no
+// symbol but the last may complete the block, because what follows a complete block is the next block's DC code.
+#ifndef JA_CHAIN_BITS
+#define JA_CHAIN_BITS 10
+#endif
+constexpr int kChainBits = JA_CHAIN_BITS, kChainSize = 1 << kChainBits;
+static_assert(kChainBits >= 10 && kChainBits <= 15, "skip is a 4-bit field; look_ac is a 10-bit table");
+inline void build_chain_table(const Huffman &h, uint64_t *t)
+{
+    for (int w = 0; w < kChainSize; ++w) {
+        int pos = 0, advance = 0, guard = 0, stores = 0, eob = 0, symbols = 0;
+        int at[2] = {0, 0}, val[2] = {0, 0};
+        for (;;) {
+            const uint32_t e = h.look_ac[((w << pos) & (kChainSize - 1)) >> (kChainBits - 10)];
+            const int l = (int)(e & 31), n = (int)(e >> 5) & 31;
+            if (!e || pos + l > kChainBits || advance > 63) break;
+            if (n && (e & 1024) && stores == 2) break;
+            guard = advance;
+            pos += l;
+            ++symbols;
+            if (n == 0) { eob = 1; break; }
+            if (e & 1024) { at[stores] = advance + n - 1; val[stores++] = (int)(e >> 16); }
+            advance += n;
+        }
+        if (stores == 1) { at[1] = at[0]; val[1] = val[0]; }
+        t[w] = symbols == 0 ? 0
+             : (uint64_t)pos | ((uint64_t)at[0] << 4) | ((uint64_t)at[1] << 11) | ((uint64_t)advance << 18) | ((uint64_t)eob << 25)
+               | ((uint64_t)guard << 26) | ((uint64_t)(uint16_t)val[0] << 32) | ((uint64_t)(uint16_t)val[1] << 48);
+    }
+}
+// DC difference + "nothing but zeros behind it" (ZRLs, if any, and the EOB) over the same window: bits 0-3 bits to skip
+// (0: general path), bit 6 the block is complete, bits 16-31 the difference.
+inline void build_dc_table(const Huffman &d, const Huffman &a, uint32_t *t)
+{
+    for (int w = 0; w < kChainSize; ++w) {
+        const int32_t e = d.look_dc[w >> (kChainBits - 10)];
+        t[w] = 0;
+        if (!e) continue;
+        const int l = e & 31;
+        t[w] = (uint32_t)l | ((uint32_t)(uint16_t)(int16_t)(e >> 8) << 16);
+        int pos = l, k = 1;
+        for (;;) {
+            const uint32_t e2 = a.look_ac[((w << pos) & (kChainSize - 1)) >> (kChainBits - 10)];
+            const int l2 = (int)(e2 & 31), n2 = (int)(e2 >> 5) & 31;
+            if (!e2 || pos + l2 > kChainBits || (e2 & 1024) || k > 63) break;
+            pos += l2;
+            if (n2 == 0) { t[w] = (uint32_t)pos | 64u | ((uint32_t)(uint16_t)(int16_t)(e >> 8) << 16); break; }
+            k += n2;                                            // ZRL
+        }
+    }
+}
 
 inline int extend(int v, int s) { return (s == 0 || v >= (1 << (s - 1))) ? v : v - (1 << s) + 1; }  // T.81 F.2.2.1
 
@@ -529,28 +655,147 @@ struct Decoder {
         return JPEG_AMD_OK;
         };   // run_interval
 
+        // Sequential scans whose restart markers are all in place (or that have none): one restart interval from its own
+        // bytes [b, e), on a copy without stuffing.  A block is decoded into a local buffer (zero, then its few coefficients)
+        // and copied out whole, so the plane is written once, front to back, and never read.
+        const bool fast_sequential = !progressive && max_scans == 0x7fffffff;
+        std::vector<uint64_t> pair_tables;
+        std::vector<uint32_t> dc_tables;
+        const uint64_t *pair_of[16];
+        const uint32_t *dcx_of[16];
+        if (fast_sequential) {
+            for (int si = 0; si < nslots; ++si)
+                if (!dc[slots[si].td].defined || !ac[slots[si].ta].defined) return JPEG_AMD_EINVAL;
+            pair_tables.resize((size_t)kChainSize * 4);
+            dc_tables.resize((size_t)kChainSize * 16);
+            bool have_pair[4] = {false, false, false, false}, have_dcx[16] = {};
+            for (int si = 0; si < nslots; ++si) {
+                const int td = slots[si].td, ta = slots[si].ta, both = td * 4 + ta;
+                if (!have_pair[ta]) { build_chain_table(ac[ta], pair_tables.data() + (size_t)kChainSize * ta); have_pair[ta] = true; }
+                if (!have_dcx[both]) { build_dc_table(dc[td], ac[ta], dc_tables.data() + (size_t)kChainSize * both); have_dcx[both] = true; }
+                pair_of[si] = pair_tables.data() + (size_t)kChainSize * ta;
+                dcx_of[si] = dc_tables.data() + (size_t)kChainSize * both;
+            }
+        }
+        auto seq_interval = [&](const uint8_t *b, const uint8_t *e, long mcu0, long mcu1, std::vector<uint8_t> &scratch) -> int {
+            const uint8_t *clean_end = unstuff(b, e, scratch);
+            CleanReader br{scratch.data(), clean_end + 8};
+            size_t plane_bytes = 0;
+            bool streaming = true;
+            for (int j = 0; j < ns; ++j) {
+                streaming = streaming && (reinterpret_cast<uintptr_t>(sc[j].c->coef) & 15) == 0;
+                plane_bytes += (size_t)128 * sc[j].c->ux * sc[j].c->uy;
+            }
+            streaming = streaming && plane_bytes >= ((size_t)1 << 20);     // smaller planes stay in this core's cache
+            int pred[4] = {0, 0, 0, 0};
+            alignas(64) int16_t tmp[128];      // [64, 128): where the stores of a damaged stream land that run past the block
+            std::memset(tmp, 0, sizeof tmp);
+            int my = (int)(mcu0 / mcux), mx = (int)(mcu0 - (long)my * mcux) - 1;
+            for (long mcu = mcu0; mcu < mcu1; ++mcu) {
+                if (++mx == mcux) { mx = 0; ++my; }
+                for (int si = 0; si < nslots; ++si) {
+                    const Slot &sl = slots[si];
+                    Component *c = sl.c;
+                    const int x = ns > 1 ? mx * c->fx + sl.bx : mx, y = ns > 1 ? my * c->fy + sl.by : my;
+                    const int ci = (int)(c - comps.data());
+                    // ---- DC (T.81 F.2.2.1), together with an EOB right behind it where both fit the window ----
+                    br.refill();
+                    const uint32_t ed = dcx_of[si][br.acc >> (64 - kChainBits)];
+                    bool done = false;
+                    int budget = 0;                                      // valid bits a lookup may still count on
+                    if (ed & 15) {
+                        br.skip((int)(ed & 15));
+                        budget = 56 - (int)(ed & 15);
+                        pred[ci] += (int32_t)ed >> 16;
+                        done = (ed & 64) != 0;
+                    } else {
+                        const int t = br.symbol(dc[sl.td]);
+                        if (t > 16) return JPEG_AMD_EINVAL;
+                        if (t) pred[ci] += br.magnitude(t);
+                    }
+                    tmp[0] = (int16_t)pred[ci];
+                    // ---- AC (T.81 F.2.2.2) ----
+                    if (!done) {
+                        const Huffman &h = ac[sl.ta];
+                        const uint64_t *chains = pair_of[si];
+                        int k = 1;
+                        while (k < 64) {
+                            if (budget < kChainBits) { br.refill(); budget = 56; }
+                            uint64_t en = chains[br.acc >> (64 - kChainBits)];
+                            if (__builtin_expect(k + (int)((en >> 26) & 63) > 63, 0)) {
+                                // a symbol in the middle of the entry would complete the block: one symbol at a time
+                                const uint32_t e1 = h.look_ac[br.peek10()];
+                                const uint64_t n1 = (e1 >> 5) & 31;
+                                en = e1 == 0 ? 0 : (uint64_t)(e1 & 31) | (n1 << 18) | (n1 ? 0 : 1ull << 25)
+                                     | (e1 & 1024 ? ((n1 - 1) << 4) | ((n1 - 1) << 11) | ((uint64_t)(e1 >> 16) << 32) | ((uint64_t)(e1 >> 16) << 48) : 0);
+                            }
+                            const int n = (int)(en & 15);
+                            if (__builtin_expect(n == 0, 0)) {           // a code + magnitude longer than 10 bits: the long way
+                                br.refill();
+                                budget = 0;
+                                const int rs = br.symbol(h);
+                                const int r = rs >> 4, sz = rs & 15;
+                                if (sz == 0) {
+                                    if (r != 15) break;
+                                    k += 16;
+                                    continue;
+                                }
+                                k += r;
+                                tmp[k] = (int16_t)br.magnitude(sz);       // k <= 63 + 15
+                                ++k;
+                                continue;
+                            }
+                            br.skip(n);
+                            budget -= n;
+                            tmp[k + ((en >> 4) & 127)] = (int16_t)(en >> 32);
+                            tmp[k + ((en >> 11) & 127)] = (int16_t)(en >> 48);
+                            k += (int)(en >> 18) & 127;
+                            if (en & (1ull << 25)) break;
+                        }
+                    }
+                    if (x < c->ux && y < c->uy) store_block(c->coef + (size_t)64 * ((size_t)c->ux * y + x), tmp, streaming);
+                    std::memset(tmp, 0, 128);
+                }
+            }
+#if JA_X86_STREAMING
+            if (streaming) _mm_sfence();
+#endif
+            return JPEG_AMD_OK;
+        };
+
         const long nintervals = (total + ri - 1) / ri;
         // a thread is worth starting for a few thousand blocks, not less
         const long useful = std::min<long>(nthreads, std::min<long>(nintervals, auto_threads ? total * nslots / 4096 : nintervals));
-        if (useful > 1) {
+        if (useful > 1 || fast_sequential) {
             // Restart-interval-parallel decoding: the intervals of a scan are
             // independent bit streams separated by RSTn markers.  Only when every marker is
-            // where it should be; a damaged stream takes the sequential path below, which
+            // where it should be; a damaged stream takes the careful path below, which
             // resynchronises like the reference.
             std::vector<const uint8_t *> starts{ecs};
-            for (const uint8_t *q = ecs; q + 1 < end;) {
-                q = static_cast<const uint8_t *>(std::memchr(q, 0xff, (size_t)(end - 1 - q)));
-                if (!q) break;
-                if (q[1] >= 0xd0 && q[1] <= 0xd7) starts.push_back(q + 2);
-                q += q[1] == 0xff ? 1 : 2;          // 0xFF fill bytes may precede a marker
-            }
+            if (nintervals > 1)
+                for (const uint8_t *q = ecs; q + 1 < end;) {
+                    q = static_cast<const uint8_t *>(std::memchr(q, 0xff, (size_t)(end - 1 - q)));
+                    if (!q) break;
+                    if (q[1] >= 0xd0 && q[1] <= 0xd7) starts.push_back(q + 2);
+                    q += q[1] == 0xff ? 1 : 2;          // 0xFF fill bytes may precede a marker
+                }
             if ((long)starts.size() == nintervals) {
                 std::vector<int> status((size_t)nintervals, JPEG_AMD_OK);
-                const int t_n = (int)useful;
+                const int t_n = (int)std::max<long>(1, useful);
                 auto work = [&](int t) {
-                    for (long k = t; k < nintervals; k += t_n) {
-                        BitReader br(starts[(size_t)k], k + 1 < nintervals ? starts[(size_t)k + 1] - 2 : end);
-                        status[(size_t)k] = run_interval(br, k * ri, std::min(total, (k + 1) * ri));
+                    try {
+                        std::vector<uint8_t> scratch;
+                        for (long k = t; k < nintervals; k += t_n) {
+                            const uint8_t *b = starts[(size_t)k], *e = k + 1 < nintervals ? starts[(size_t)k + 1] - 2 : end;
+                            const long mcu0 = k * ri, mcu1 = std::min(total, (k + 1) * ri);
+                            if (fast_sequential) status[(size_t)k] = seq_interval(b, e, mcu0, mcu1, scratch);
+                            else {
+                                BitReader br(b, e);
+                                status[(size_t)k] = run_interval(br, mcu0, mcu1);
+                            }
+                        }
+                    } catch (...) {
+                        status[(size_t)t] = JPEG_AMD_ENOMEM;   // (t < t_n <= nintervals)
                     }
                 };
                 std::vector<std::thread> pool;

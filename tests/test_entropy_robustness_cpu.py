@@ -118,3 +118,67 @@ def test_streaming_a_large_scan_in_small_pieces_stays_linear():
         assert time.perf_counter() - t0 < 20.0
     finally:
         lib.jpeg_amd_stream_destroy(s)
+
+
+def _decode(lib, data, info, careful, threads=1):
+    planes = [np.zeros((info.units_y[c], info.units_x[c], 64), np.int16) for c in range(info.ncomponents)]
+    quanta = np.zeros((4, 64), np.uint16)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+    # max_scans > 0 (a preview after N scans, here more than the file has) takes the careful bit reader: stuffing, markers
+    # and the end of the data tested byte by byte, one symbol per lookup
+    st = lib.jpeg_amd_jpeg_decode_spectral_partial(buf, len(data), _lib.ptr_array([p.ctypes.data for p in planes]),
+                                                   quanta.ctypes.data, None, threads, 1000 if careful else 0)
+    return st, planes
+
+
+def test_fast_sequential_path_agrees_with_the_careful_reader_on_damaged_streams():
+    # the fast path of sequential scans (stuffing removed up front, two AC symbols per lookup, DC + EOB in one) against the
+    # byte-by-byte reader, on intact files and on the same files with flipped bits, garbage runs, stray 0xFF bytes and
+    # markers, a truncated scan, and a removed restart marker (which sends both down the resynchronising path)
+    lib = _lib.lib()
+    rng = np.random.default_rng(2024)
+    for name in ["color-sequential-1.jpg", "color-sequential-3.jpg", "color-sequential-restart.jpg",
+                 "grayscale-sequential-1.jpg", "grayscale-sequential-restart.jpg", "karlie-kwk-2019.jpg"]:
+        data = bytearray(fixture_bytes(name))
+        info = _lib.FrameInfo()
+        buf0 = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+        assert lib.jpeg_amd_jpeg_inspect(buf0, len(data), C.byref(info)) == 0
+        if info.process == 2:
+            continue
+        sos = data.index(b"\xff\xda")
+        start = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+        end = len(data) - 2
+        for trial in range(40):
+            d = bytearray(data)
+            kind = trial % 8
+            if kind == 1:                                   # a few flipped bits
+                for _ in range(int(rng.integers(1, 6))):
+                    d[int(rng.integers(start, end))] ^= 1 << int(rng.integers(8))
+            elif kind == 2:                                 # a run of bytes without 0xFF
+                lo = int(rng.integers(start, max(start + 1, end - 64)))
+                d[lo:lo + 48] = bytes(rng.integers(0, 0xff, 48).astype(np.uint8).tolist())
+            elif kind == 3:                                 # stray 0xFF bytes: stuffed, unstuffed, doubled
+                lo = int(rng.integers(start, end - 4))
+                d[lo:lo + 3] = [b"\xff\x00\xff", b"\xff\xff\x00", b"\xff\x01\x02"][int(rng.integers(3))]
+            elif kind == 4:                                 # a marker in the middle of the data
+                lo = int(rng.integers(start, end - 2))
+                d[lo:lo + 2] = bytes([0xff, int(rng.choice([0xd0, 0xd3, 0xd7, 0xc4, 0xfe]))])
+            elif kind == 5:                                 # truncated
+                d = d[:int(rng.integers(start + 1, end))]
+            elif kind == 6:                                 # one restart marker gone (if there is one)
+                marks = [i for i in range(start, end - 1) if d[i] == 0xff and 0xd0 <= d[i + 1] <= 0xd7]
+                if marks:
+                    i = marks[int(rng.integers(len(marks)))]
+                    d[i:i + 2] = b"\x12\x34"
+            elif kind == 7:                                 # all ones to the end
+                lo = int(rng.integers(start, end))
+                d[lo:end] = b"\xfe" * (end - lo)
+            a = _decode(lib, d, info, careful=False)
+            b = _decode(lib, d, info, careful=True)
+            assert a[0] == b[0], (name, trial, a[0], b[0])
+            if a[0] == 0:
+                for c, (p, q) in enumerate(zip(a[1], b[1])):
+                    assert (p == q).all(), (name, trial, kind, c, np.argwhere(p != q)[:3])
+            if info.restart_interval and kind != 6:
+                t = _decode(lib, d, info, careful=False, threads=3)
+                assert t[0] == a[0] and all((p == q).all() for p, q in zip(t[1], a[1])), (name, trial)

@@ -677,92 +677,117 @@ struct Decoder {
                 dcx_of[si] = dc_tables.data() + (size_t)kChainSize * both;
             }
         }
-        auto seq_interval = [&](const uint8_t *b, const uint8_t *e, long mcu0, long mcu1, std::vector<uint8_t> &scratch) -> int {
+        // One restart interval in flight: where its reader is, and which block comes next.
+        struct Walk {
+            CleanReader br{nullptr, nullptr};
+            int pred[4] = {0, 0, 0, 0};
+            long mcu = 0, mcu1 = 0;
+            int mx = 0, my = 0, si = 0;
+            bool streaming = false;
+            alignas(64) int16_t tmp[128];      // [64, 128): where the stores of a damaged stream land that run past the block
+        };
+        auto begin_walk = [&](Walk &w, const uint8_t *b, const uint8_t *e, long mcu0, long mcu1, std::vector<uint8_t> &scratch) {
             const uint8_t *clean_end = unstuff(b, e, scratch);
-            CleanReader br{scratch.data(), clean_end + 8};
+            w.br = CleanReader{scratch.data(), clean_end + 8};
             size_t plane_bytes = 0;
-            bool streaming = true;
+            w.streaming = true;
             for (int j = 0; j < ns; ++j) {
-                streaming = streaming && (reinterpret_cast<uintptr_t>(sc[j].c->coef) & 15) == 0;
+                w.streaming = w.streaming && (reinterpret_cast<uintptr_t>(sc[j].c->coef) & 15) == 0;
                 plane_bytes += (size_t)128 * sc[j].c->ux * sc[j].c->uy;
             }
-            streaming = streaming && plane_bytes >= ((size_t)1 << 20);     // smaller planes stay in this core's cache
-            int pred[4] = {0, 0, 0, 0};
-            alignas(64) int16_t tmp[128];      // [64, 128): where the stores of a damaged stream land that run past the block
-            std::memset(tmp, 0, sizeof tmp);
-            int my = (int)(mcu0 / mcux), mx = (int)(mcu0 - (long)my * mcux) - 1;
-            for (long mcu = mcu0; mcu < mcu1; ++mcu) {
-                if (++mx == mcux) { mx = 0; ++my; }
-                for (int si = 0; si < nslots; ++si) {
-                    const Slot &sl = slots[si];
-                    Component *c = sl.c;
-                    const int x = ns > 1 ? mx * c->fx + sl.bx : mx, y = ns > 1 ? my * c->fy + sl.by : my;
-                    const int ci = (int)(c - comps.data());
-                    // ---- DC (T.81 F.2.2.1), together with an EOB right behind it where both fit the window ----
-                    br.refill();
-                    const uint32_t ed = dcx_of[si][br.acc >> (64 - kChainBits)];
-                    bool done = false;
-                    int budget = 0;                                      // valid bits a lookup may still count on
-                    if (ed & 15) {
-                        br.skip((int)(ed & 15));
-                        budget = 56 - (int)(ed & 15);
-                        pred[ci] += (int32_t)ed >> 16;
-                        done = (ed & 64) != 0;
-                    } else {
-                        const int t = br.symbol(dc[sl.td]);
-                        if (t > 16) return JPEG_AMD_EINVAL;
-                        if (t) pred[ci] += br.magnitude(t);
+            w.streaming = w.streaming && plane_bytes >= ((size_t)1 << 20);     // smaller planes stay in this core's cache
+            std::memset(w.tmp, 0, sizeof w.tmp);
+            w.mcu = mcu0; w.mcu1 = mcu1;
+            w.my = (int)(mcu0 / mcux); w.mx = (int)(mcu0 - (long)w.my * mcux);
+            w.si = 0;
+        };
+        // the next block of a walk (slot w.si of MCU w.mcu)
+        auto next_block = [&](Walk &w) __attribute__((always_inline)) -> int {
+            const Slot &sl = slots[w.si];
+            Component *c = sl.c;
+            const int x = ns > 1 ? w.mx * c->fx + sl.bx : w.mx, y = ns > 1 ? w.my * c->fy + sl.by : w.my;
+            const int ci = (int)(c - comps.data());
+            // ---- DC (T.81 F.2.2.1), together with an EOB right behind it where both fit the window ----
+            w.br.refill();
+            const uint32_t ed = dcx_of[w.si][w.br.acc >> (64 - kChainBits)];
+            bool done = false;
+            int budget = 0;                                      // valid bits a lookup may still count on
+            if (ed & 15) {
+                w.br.skip((int)(ed & 15));
+                budget = 56 - (int)(ed & 15);
+                w.pred[ci] += (int32_t)ed >> 16;
+                done = (ed & 64) != 0;
+            } else {
+                const int t = w.br.symbol(dc[sl.td]);
+                if (t > 16) return JPEG_AMD_EINVAL;
+                if (t) w.pred[ci] += w.br.magnitude(t);
+            }
+            w.tmp[0] = (int16_t)w.pred[ci];
+            // ---- AC (T.81 F.2.2.2) ----
+            if (!done) {
+                const Huffman &h = ac[sl.ta];
+                const uint64_t *chains = pair_of[w.si];
+                int k = 1;
+                while (k < 64) {
+                    if (budget < kChainBits) { w.br.refill(); budget = 56; }
+                    uint64_t en = chains[w.br.acc >> (64 - kChainBits)];
+                    if (__builtin_expect(k + (int)((en >> 26) & 63) > 63, 0)) {
+                        // a symbol in the middle of the entry would complete the block: one symbol at a time
+                        const uint32_t e1 = h.look_ac[w.br.peek10()];
+                        const uint64_t n1 = (e1 >> 5) & 31;
+                        en = e1 == 0 ? 0 : (uint64_t)(e1 & 31) | (n1 << 18) | (n1 ? 0 : 1ull << 25)
+                             | (e1 & 1024 ? ((n1 - 1) << 4) | ((n1 - 1) << 11) | ((uint64_t)(e1 >> 16) << 32) | ((uint64_t)(e1 >> 16) << 48) : 0);
                     }
-                    tmp[0] = (int16_t)pred[ci];
-                    // ---- AC (T.81 F.2.2.2) ----
-                    if (!done) {
-                        const Huffman &h = ac[sl.ta];
-                        const uint64_t *chains = pair_of[si];
-                        int k = 1;
-                        while (k < 64) {
-                            if (budget < kChainBits) { br.refill(); budget = 56; }
-                            uint64_t en = chains[br.acc >> (64 - kChainBits)];
-                            if (__builtin_expect(k + (int)((en >> 26) & 63) > 63, 0)) {
-                                // a symbol in the middle of the entry would complete the block: one symbol at a time
-                                const uint32_t e1 = h.look_ac[br.peek10()];
-                                const uint64_t n1 = (e1 >> 5) & 31;
-                                en = e1 == 0 ? 0 : (uint64_t)(e1 & 31) | (n1 << 18) | (n1 ? 0 : 1ull << 25)
-                                     | (e1 & 1024 ? ((n1 - 1) << 4) | ((n1 - 1) << 11) | ((uint64_t)(e1 >> 16) << 32) | ((uint64_t)(e1 >> 16) << 48) : 0);
-                            }
-                            const int n = (int)(en & 15);
-                            if (__builtin_expect(n == 0, 0)) {           // a code + magnitude longer than 10 bits: the long way
-                                br.refill();
-                                budget = 0;
-                                const int rs = br.symbol(h);
-                                const int r = rs >> 4, sz = rs & 15;
-                                if (sz == 0) {
-                                    if (r != 15) break;
-                                    k += 16;
-                                    continue;
-                                }
-                                k += r;
-                                tmp[k] = (int16_t)br.magnitude(sz);       // k <= 63 + 15
-                                ++k;
-                                continue;
-                            }
-                            br.skip(n);
-                            budget -= n;
-                            tmp[k + ((en >> 4) & 127)] = (int16_t)(en >> 32);
-                            tmp[k + ((en >> 11) & 127)] = (int16_t)(en >> 48);
-                            k += (int)(en >> 18) & 127;
-                            if (en & (1ull << 25)) break;
+                    const int n = (int)(en & 15);
+                    if (__builtin_expect(n == 0, 0)) {           // a code + magnitude longer than 10 bits: the long way
+                        w.br.refill();
+                        budget = 0;
+                        const int rs = w.br.symbol(h);
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r != 15) break;
+                            k += 16;
+                            continue;
                         }
+                        k += r;
+                        w.tmp[k] = (int16_t)w.br.magnitude(sz);       // k <= 63 + 15
+                        ++k;
+                        continue;
                     }
-                    if (x < c->ux && y < c->uy) store_block(c->coef + (size_t)64 * ((size_t)c->ux * y + x), tmp, streaming);
-                    std::memset(tmp, 0, 128);
+                    w.br.skip(n);
+                    budget -= n;
+                    w.tmp[k + ((en >> 4) & 127)] = (int16_t)(en >> 32);
+                    w.tmp[k + ((en >> 11) & 127)] = (int16_t)(en >> 48);
+                    k += (int)(en >> 18) & 127;
+                    if (en & (1ull << 25)) break;
                 }
             }
-#if JA_X86_STREAMING
-            if (streaming) _mm_sfence();
-#endif
+            if (x < c->ux && y < c->uy) store_block(c->coef + (size_t)64 * ((size_t)c->ux * y + x), w.tmp, w.streaming);
+            std::memset(w.tmp, 0, 128);
+            if (++w.si == nslots) {
+                w.si = 0;
+                ++w.mcu;
+                if (++w.mx == mcux) { w.mx = 0; ++w.my; }
+            }
             return JPEG_AMD_OK;
         };
-
+        auto end_walk = [&](Walk &w) {
+#if JA_X86_STREAMING
+            if (w.streaming) _mm_sfence();
+#else
+            (void)w;
+#endif
+        };
+        auto seq_interval = [&](const uint8_t *b, const uint8_t *e, long mcu0, long mcu1, std::vector<uint8_t> &scratch) -> int {
+            Walk w;
+            begin_walk(w, b, e, mcu0, mcu1, scratch);
+            while (w.mcu < w.mcu1) {
+                const int st = next_block(w);
+                if (st != JPEG_AMD_OK) return st;
+            }
+            end_walk(w);
+            return JPEG_AMD_OK;
+        };
         const long nintervals = (total + ri - 1) / ri;
         // a thread is worth starting for a few thousand blocks, not less
         const long useful = std::min<long>(nthreads, std::min<long>(nintervals, auto_threads ? total * nslots / 4096 : nintervals));
@@ -785,8 +810,11 @@ struct Decoder {
                 auto work = [&](int t) {
                     try {
                         std::vector<uint8_t> scratch;
-                        for (long k = t; k < nintervals; k += t_n) {
-                            const uint8_t *b = starts[(size_t)k], *e = k + 1 < nintervals ? starts[(size_t)k + 1] - 2 : end;
+                        auto first = [&](long i) { return starts[(size_t)i]; };
+                        auto last = [&](long i) { return i + 1 < nintervals ? starts[(size_t)i + 1] - 2 : end; };
+                        long k = t;
+                        for (; k < nintervals; k += t_n) {
+                            const uint8_t *b = first(k), *e = last(k);
                             const long mcu0 = k * ri, mcu1 = std::min(total, (k + 1) * ri);
                             if (fast_sequential) status[(size_t)k] = seq_interval(b, e, mcu0, mcu1, scratch);
                             else {

@@ -27,8 +27,16 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
+
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#define JA_X86_SSE2 1
+#else
+#define JA_X86_SSE2 0
+#endif
 
 #include "../../include/jpeg_amd.h"
 
@@ -186,9 +194,7 @@ inline void compact(int16_t x, int &binade, unsigned &tail)
 
 constexpr uint32_t kRestartToken = 0xffffffffu;   // table field 7 does not occur otherwise
 
-struct Sink {   // either counts symbols or writes bits
-    long *dc_freq = nullptr, *ac_freq = nullptr;
-    const Codebook *dc = nullptr, *ac = nullptr;
+struct Sink {   // writes bits: MSB first, 0xFF bytes stuffed
     std::vector<uint8_t> *out = nullptr;
     uint64_t acc = 0;
     int nacc = 0;
@@ -200,60 +206,77 @@ struct Sink {   // either counts symbols or writes bits
         out->insert(out->end(), buf, buf + nbuf);
         nbuf = 0;
     }
-    void bits(unsigned v, int n)          // n <= 32
+    void byte(uint8_t b)
+    {
+        buf[nbuf++] = b;
+        if (b == 0xff) buf[nbuf++] = 0x00;
+    }
+    void bits(unsigned v, int n)          // n <= 32; up to 31 bits wait in `acc` for the next call
     {
         if (n == 0) return;
         acc = (acc << n) | ((uint64_t)v & ((1ull << n) - 1ull));
         nacc += n;
+        if (nacc < 32) return;
+        if (nbuf > (int)sizeof buf - 16) spill();
+        const uint32_t w = (uint32_t)(acc >> (nacc - 32));   // four whole bytes at a time; stuffing only where a 0xFF is among them
+        nacc -= 32;
+        if (!has_ff(w)) {
+            buf[nbuf] = (uint8_t)(w >> 24); buf[nbuf + 1] = (uint8_t)(w >> 16); buf[nbuf + 2] = (uint8_t)(w >> 8); buf[nbuf + 3] = (uint8_t)w;
+            nbuf += 4;
+        } else {
+            byte((uint8_t)(w >> 24)); byte((uint8_t)(w >> 16)); byte((uint8_t)(w >> 8)); byte((uint8_t)w);
+        }
+    }
+    static bool has_ff(uint32_t w)        // a byte of w is 0xFF  <=>  a byte of ~w is zero
+    {
+        const uint32_t x = ~w;
+        return ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
+    }
+    void flush_bytes()                    // the whole bytes still waiting
+    {
         if (nbuf > (int)sizeof buf - 16) spill();
         while (nacc >= 8) {
-            const uint8_t b = (uint8_t)(acc >> (nacc - 8));
-            buf[nbuf++] = b;
-            if (b == 0xff) buf[nbuf++] = 0x00;
+            byte((uint8_t)(acc >> (nacc - 8)));
             nacc -= 8;
+        }
+    }
+    void pad()                            // to a byte boundary with 1-bits, everything out of `acc`
+    {
+        flush_bytes();
+        if (nacc > 0) {
+            const int fill = 8 - nacc;
+            acc = (acc << fill) | ((1u << fill) - 1u);
+            nacc = 8;
+            flush_bytes();
         }
     }
     void finish()
     {
-        if (nacc > 0) bits((1u << (8 - nacc)) - 1u, 8 - nacc);   // pad with 1-bits
+        pad();
         spill();
     }
     int rst = 0;
     void restart_marker()                                        // end of a restart interval: pad, RSTm
     {
-        if (nacc > 0) bits((1u << (8 - nacc)) - 1u, 8 - nacc);
+        pad();
         if (nbuf > (int)sizeof buf - 16) spill();
         buf[nbuf++] = 0xff;
         buf[nbuf++] = (uint8_t)(0xd0 + rst);
         rst = (rst + 1) & 7;
     }
-    // Sequential scans walk the coefficients ONCE: the statistics pass also records every symbol
-    // as a 32-bit token -- symbol, table (selector + DC/AC), number of magnitude bits, the bits --
-    // and the coding pass only replays the tokens against the finished tables.
-    std::vector<uint32_t> *tokens = nullptr;
-    int dc_sel = 0, ac_sel = 0;
-    void dc_symbol(int sym, unsigned tail, int n)
+    // the coding pass of a sequential scan: the tokens of the statistics pass (tokenize_block) against the finished tables
+    void replay(const uint32_t *toks, size_t ntoks, const Codebook *dcb, const Codebook *acb)
     {
-        if (out) bits((unsigned)dc->code[sym] << n | tail, dc->length[sym] + n);   // code and magnitude bits together
-        else {
-            ++dc_freq[sym];
-            if (tokens) tokens->push_back((uint32_t)sym | (uint32_t)n << 8 | (uint32_t)dc_sel << 13 | tail << 16);
-        }
-    }
-    void ac_symbol(int sym, unsigned tail, int n)
-    {
-        if (out) bits((unsigned)ac->code[sym] << n | tail, ac->length[sym] + n);
-        else {
-            ++ac_freq[sym];
-            if (tokens) tokens->push_back((uint32_t)sym | (uint32_t)n << 8 | (uint32_t)(4 + ac_sel) << 13 | tail << 16);
-        }
-    }
-    void replay(const std::vector<uint32_t> &toks, const Codebook *dcb, const Codebook *acb)
-    {
-        for (const uint32_t t : toks) {
+        const Codebook *const books[8] = {dcb, dcb + 1, dcb + 2, dcb + 3, acb, acb + 1, acb + 2, acb + 3};
+        for (size_t i = 0; i < ntoks; ++i) {
+            const uint32_t t = toks[i];
             if (t == kRestartToken) { restart_marker(); continue; }
-            const int sym = t & 0xff, n = (t >> 8) & 31, table = (t >> 13) & 7;
-            const Codebook &cb = table < 4 ? dcb[table] : acb[table - 4];
+            const int sym = t & 0xff, n = (t >> 8) & 31;
+            const Codebook &cb = *books[(t >> 13) & 7];
+            if ((t & 0x80ff) == 0x80f0) {                           // an AC table's ZRL: 1 ... 3 of them
+                for (unsigned k = t >> 16; k > 0; --k) bits(cb.code[0xf0], cb.length[0xf0]);
+                continue;
+            }
             bits((unsigned)cb.code[sym] << n | (t >> 16), cb.length[sym] + n);
         }
         finish();
@@ -262,26 +285,77 @@ struct Sink {   // either counts symbols or writes bits
 
 const int16_t kZeroBlock[64] = {0};
 
-void encode_block(const int16_t *blk, int16_t &pred, Sink &s)
+// The symbols of one block, for the statistics pass of a sequential scan: found from a 64-bit mask of the nonzero
+// coefficients (sixteen at a time with SSE2 where there is one) instead of 63 tests, counted, and recorded as 32-bit tokens
+// -- symbol, table (selector + DC/AC), number of magnitude bits, the bits -- through a pointer.  The coding pass only replays
+// the tokens against the finished tables.
+struct TokenList {
+    std::unique_ptr<uint32_t[]> storage;   // uninitialised, grown by doubling; the first n entries are tokens
+    size_t capacity = 0, n = 0;
+    uint32_t *room(size_t more)            // space for `more` tokens behind the n that are there
+    {
+        if (n + more > capacity) {
+            const size_t grown = std::max(capacity * 2, n + more + 65536);
+            std::unique_ptr<uint32_t[]> bigger(new uint32_t[grown]);
+            if (n) std::memcpy(bigger.get(), storage.get(), n * sizeof(uint32_t));
+            storage.swap(bigger);
+            capacity = grown;
+        }
+        return storage.get() + n;
+    }
+};
+
+inline uint64_t nonzero_mask(const int16_t *blk)
 {
+    uint64_t m = 0;
+#if JA_X86_SSE2
+    const __m128i zero = _mm_setzero_si128();
+    for (int i = 0; i < 4; ++i) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(blk + 16 * i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(blk + 16 * i + 8));
+        const unsigned zeros = (unsigned)_mm_movemask_epi8(_mm_packs_epi16(_mm_cmpeq_epi16(a, zero), _mm_cmpeq_epi16(b, zero)));
+        m |= (uint64_t)(~zeros & 0xffffu) << (16 * i);
+    }
+#else
+    for (int z = 0; z < 64; ++z) m |= (uint64_t)(blk[z] != 0) << z;
+#endif
+    return m;
+}
+
+inline void tokenize_block(const int16_t *blk, int16_t &pred, TokenList &list, long *dc_freq, long *ac_freq, int dc_sel, int ac_sel)
+{
+    uint32_t *t = list.room(70);                       // DC + 63 coefficients + 3 ZRLs + EOB at most
+    const uint32_t *const t0 = t;
     int binade;
     unsigned tail;
     compact((int16_t)(blk[0] - pred), binade, tail);   // wrapping 16-bit difference
     pred = blk[0];
-    s.dc_symbol(binade, tail, binade);
-    int zeroes = 0;
-    for (int z = 1; z < 64; ++z) {
-        const int16_t c = blk[z];
-        if (c == 0) {
-            if (zeroes == 15) { s.ac_symbol(0xf0, 0, 0); zeroes = 0; }
-            else ++zeroes;
-        } else {
-            compact(c, binade, tail);
-            s.ac_symbol(zeroes << 4 | binade, tail, binade);
-            zeroes = 0;
+    ++dc_freq[binade];
+    *t++ = (uint32_t)binade | (uint32_t)binade << 8 | (uint32_t)dc_sel << 13 | tail << 16;
+    const uint32_t ac_table = (uint32_t)(4 + ac_sel) << 13;
+    int prev = 0;                                      // the last coefficient that has been coded
+    for (uint64_t m = nonzero_mask(blk) & ~1ull; m; m &= m - 1) {
+        const int z = __builtin_ctzll(m);
+        int run = z - prev - 1;
+        if (run >= 16) {                               // up to three ZRLs: one token, the count where the magnitude bits would be
+            ac_freq[0xf0] += run >> 4;
+            *t++ = 0xf0u | ac_table | (uint32_t)(run >> 4) << 16;
+            run &= 15;
         }
+        compact(blk[z], binade, tail);
+        const int sym = run << 4 | binade;
+        ++ac_freq[sym];
+        *t++ = (uint32_t)sym | (uint32_t)binade << 8 | ac_table | tail << 16;
+        prev = z;
     }
-    if (zeroes > 0) s.ac_symbol(0x00, 0, 0);   // EOB (run of 1 block)
+    int run = 63 - prev;                               // eager ZRLs: one per complete run of 16, also in front of the EOB
+    if (run >= 16) {
+        ac_freq[0xf0] += run >> 4;
+        *t++ = 0xf0u | ac_table | (uint32_t)(run >> 4) << 16;
+        run &= 15;
+    }
+    if (run > 0) { ++ac_freq[0x00]; *t++ = ac_table; }
+    list.n += (size_t)(t - t0);
 }
 
 struct Plane {
@@ -662,46 +736,39 @@ try {
             long dc_freq[4][256], ac_freq[4][256];
             std::memset(dc_freq, 0, sizeof dc_freq);
             std::memset(ac_freq, 0, sizeof ac_freq);
-            std::vector<uint32_t> tokens;
-            auto walk = [&](bool emit, std::vector<uint8_t> *ecs, const Codebook *dcb, const Codebook *acb) {
-                Sink s;
-                s.out = emit ? ecs : nullptr;
-                if (!emit) s.tokens = &tokens;
+            TokenList tokens;
+            {
                 int16_t pred[4] = {0, 0, 0, 0};
-                auto select = [&](int j) {
-                    s.dc_freq = dc_freq[sc.dc[j]]; s.ac_freq = ac_freq[sc.ac[j]];
-                    s.dc_sel = sc.dc[j]; s.ac_sel = sc.ac[j];
-                    if (emit) { s.dc = dcb + sc.dc[j]; s.ac = acb + sc.ac[j]; }
-                };
                 long mcu = 0;
                 auto boundary = [&] {
                     if (ri && mcu && mcu % ri == 0) {
                         pred[0] = pred[1] = pred[2] = pred[3] = 0;
-                        if (s.tokens) s.tokens->push_back(kRestartToken);
+                        *tokens.room(1) = kRestartToken;
+                        ++tokens.n;
                     }
                     ++mcu;
                 };
                 if (ns == 1) {
                     const Plane &p = planes[sc.component[0]];
-                    select(0);
                     for (int y = 0; y < p.uy; ++y)
-                        for (int x = 0; x < p.ux; ++x) { boundary(); encode_block(p.at(x, y), pred[0], s); }
+                        for (int x = 0; x < p.ux; ++x) {
+                            boundary();
+                            tokenize_block(p.at(x, y), pred[0], tokens, dc_freq[sc.dc[0]], ac_freq[sc.ac[0]], sc.dc[0], sc.ac[0]);
+                        }
                 } else {
                     for (int my = 0; my < mcuy; ++my)
                         for (int mx = 0; mx < mcux; ++mx) {
                             boundary();
                             for (int j = 0; j < ns; ++j) {
                                 const Plane &p = planes[sc.component[j]];
-                                select(j);
                                 for (int by = 0; by < p.fy; ++by)
                                     for (int bx = 0; bx < p.fx; ++bx)
-                                        encode_block(p.at(mx * p.fx + bx, my * p.fy + by), pred[j], s);
+                                        tokenize_block(p.at(mx * p.fx + bx, my * p.fy + by), pred[j], tokens, dc_freq[sc.dc[j]],
+                                                       ac_freq[sc.ac[j]], sc.dc[j], sc.ac[j]);
                             }
                         }
                 }
-                if (emit) s.finish();
-            };
-            walk(false, nullptr, nullptr, nullptr);
+            }
             Codebook dcb[4], acb[4];
             bool dc_used[4] = {false, false, false, false}, ac_used[4] = {false, false, false, false};
             for (int j = 0; j < ns; ++j) { dc_used[sc.dc[j]] = true; ac_used[sc.ac[j]] = true; }
@@ -728,7 +795,7 @@ try {
             }
             sos.push_back(0); sos.push_back(63); sos.push_back(0);
             segment(out, 0xda, sos);
-            { Sink s; s.out = &out; s.replay(tokens, dcb, acb); }
+            { Sink s; s.out = &out; s.replay(tokens.storage.get(), tokens.n, dcb, acb); }
         }
     }
     out.push_back(0xff); out.push_back(0xd9);

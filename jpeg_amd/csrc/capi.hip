@@ -149,6 +149,53 @@ int stage_quanta(jpeg_amd_ctx *ctx, const uint16_t *h_quanta, int ntables, const
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// The staging the two batch entry points for files share, kept in the context between calls: two pinned host slots (the host
+// threads work in one while the device works from / into the other), two device slots, two events per slot and a second
+// stream so that uploads and downloads overlap (full-duplex PCIe).
+int ensure_file_staging(jpeg_amd_ctx *ctx, size_t slot_bytes)
+{
+    if (ctx->file_pinned_bytes < slot_bytes) {
+        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->file_pinned[i]) { (void)hipHostFree(ctx->file_pinned[i]); ctx->file_pinned[i] = nullptr; }
+            ctx->file_pinned_bytes = 0;
+            JA_HIP(ctx, hipHostMalloc(&ctx->file_pinned[i], slot_bytes, hipHostMallocDefault));
+            if (!ctx->file_done[i]) JA_HIP(ctx, hipEventCreateWithFlags(&ctx->file_done[i], hipEventDisableTiming));
+            if (!ctx->file_decoded[i]) JA_HIP(ctx, hipEventCreateWithFlags(&ctx->file_decoded[i], hipEventDisableTiming));
+        }
+        ctx->file_pinned_bytes = slot_bytes;
+    }
+    if (!ctx->file_d2h) JA_HIP(ctx, hipStreamCreateWithFlags(&ctx->file_d2h, hipStreamNonBlocking));
+    if (ctx->file_device_bytes < 2 * slot_bytes) {           // two device slots as well
+        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        JA_HIP(ctx, hipStreamSynchronize(ctx->file_d2h));
+        if (ctx->file_device) { (void)hipFree(ctx->file_device); ctx->file_device = nullptr; ctx->file_device_bytes = 0; }
+        JA_HIP(ctx, hipMalloc(&ctx->file_device, 2 * slot_bytes));
+        ctx->file_device_bytes = 2 * slot_bytes;
+    }
+    return JPEG_AMD_OK;
+}
+
+// fn(i) for i in [0, m) on up to `nthreads` threads; the calling thread takes a share, and the share of a worker that
+// cannot be started as well (fn does not throw)
+template <class F>
+void run_parallel(int nthreads, int m, F &&fn)
+{
+    const int t_n = std::max(1, std::min(nthreads, m));
+    std::vector<std::thread> pool;
+    int started = 1;
+    try {
+        pool.reserve((size_t)t_n);
+        for (int t = 1; t < t_n; ++t) { pool.emplace_back([&fn, t, m, t_n] { for (int i = t; i < m; i += t_n) fn(i); }); ++started; }
+    } catch (...) {
+    }
+    for (int t = started; t < t_n; ++t)
+        for (int i = t; i < m; i += t_n) fn(i);
+    for (int i = 0; i < m; i += t_n) fn(i);
+    for (std::thread &th : pool) th.join();
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -903,46 +950,13 @@ try {
     const size_t quanta_off = off;  off += align256((size_t)chunk * kQSlotElems * 2);
     const size_t px_off = off;      off += align256(npx * chunk);
     const size_t slot_bytes = off;
-    if (ctx->file_pinned_bytes < slot_bytes) {
-        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < 2; ++i) {
-            if (ctx->file_pinned[i]) { (void)hipHostFree(ctx->file_pinned[i]); ctx->file_pinned[i] = nullptr; }
-            ctx->file_pinned_bytes = 0;
-            JA_HIP(ctx, hipHostMalloc(&ctx->file_pinned[i], slot_bytes, hipHostMallocDefault));
-            if (!ctx->file_done[i]) JA_HIP(ctx, hipEventCreateWithFlags(&ctx->file_done[i], hipEventDisableTiming));
-            if (!ctx->file_decoded[i]) JA_HIP(ctx, hipEventCreateWithFlags(&ctx->file_decoded[i], hipEventDisableTiming));
-        }
-        ctx->file_pinned_bytes = slot_bytes;
-    }
-    if (!ctx->file_d2h) JA_HIP(ctx, hipStreamCreateWithFlags(&ctx->file_d2h, hipStreamNonBlocking));
-    if (ctx->file_device_bytes < 2 * slot_bytes) {           // two device slots as well
-        JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        JA_HIP(ctx, hipStreamSynchronize(ctx->file_d2h));
-        if (ctx->file_device) { (void)hipFree(ctx->file_device); ctx->file_device = nullptr; ctx->file_device_bytes = 0; }
-        JA_HIP(ctx, hipMalloc(&ctx->file_device, 2 * slot_bytes));
-        ctx->file_device_bytes = 2 * slot_bytes;
-    }
+    JA_TRY(ensure_file_staging(ctx, slot_bytes));
     const bool auto_threads = nthreads <= 0;
     if (auto_threads) nthreads = (int)std::thread::hardware_concurrency();
     nthreads = std::max(1, nthreads);
 
 
-    // run `fn(i)` for i in [0, m) on the pool (the calling thread takes a share)
-    // (fn does not throw; a worker that cannot be started leaves its share to the calling thread)
-    auto parallel = [&](int m, auto &&fn) {
-        const int t_n = std::min(nthreads, m);
-        std::vector<std::thread> pool;
-        int started = 1;
-        try {
-            pool.reserve((size_t)t_n);
-            for (int t = 1; t < t_n; ++t) { pool.emplace_back([&, t] { for (int i = t; i < m; i += t_n) fn(i); }); ++started; }
-        } catch (...) {
-        }
-        for (int t = started; t < t_n; ++t)
-            for (int i = t; i < m; i += t_n) fn(i);
-        for (int i = 0; i < m; i += t_n) fn(i);
-        for (std::thread &th : pool) th.join();
-    };
+    auto parallel = [&](int m, auto &&fn) { run_parallel(nthreads, m, fn); };
 
     const int nchunks = (n_images + chunk - 1) / chunk;
     int result = JPEG_AMD_OK;
@@ -1122,74 +1136,80 @@ try {
     }
     const int chunk = std::min(n_images, 32);
     if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
-    nthreads = std::max(1, std::min(nthreads, chunk));
+    nthreads = std::max(1, nthreads);
 
     const uint16_t *d_q = nullptr;
     JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
-    DeviceBag bag(ctx);
-    uint8_t *d_px = nullptr;
-    int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
-    JA_TRY(bag.alloc(npx * chunk, (void **)&d_px));
-    for (int c = 0; c < nc; ++c) JA_TRY(bag.alloc(plane[c] * 2 * chunk, (void **)&d_coef[c]));
-    // two pinned host slots for the coefficient planes: the host threads entropy-code chunk k - 1
-    // out of one while the device encodes chunk k into the other
-    struct Pinned {
-        std::vector<void *> p;
-        ~Pinned() { for (void *q : p) (void)hipHostFree(q); }
-        void *get(size_t bytes) { void *q = nullptr; if (hipHostMalloc(&q, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr; p.push_back(q); return q; }
-    } pinned;
-    int16_t *h_coef[2][JPEG_AMD_MAX_PLANES] = {};
-    hipEvent_t ready[2] = {nullptr, nullptr};
-    struct Events { hipEvent_t *e; ~Events() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } events{ready};
-    for (int sl = 0; sl < 2; ++sl) {
-        for (int c = 0; c < nc; ++c)
-            if (!(h_coef[sl][c] = static_cast<int16_t *>(pinned.get(plane[c] * 2 * chunk)))) return JPEG_AMD_ENOMEM;
-        JA_HIP(ctx, hipEventCreateWithFlags(&ready[sl], hipEventDisableTiming));
-    }
+    // slot layout (pinned and device alike): [pixels x chunk][coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk]
+    size_t coef_off[JPEG_AMD_MAX_PLANES] = {};
+    size_t off = align256(npx * chunk);
+    for (int c = 0; c < nc; ++c) { coef_off[c] = off; off += align256(plane[c] * 2 * chunk); }
+    const size_t slot_bytes = off;
+    JA_TRY(ensure_file_staging(ctx, slot_bytes));
+
     const int nchunks = (n_images + chunk - 1) / chunk;
-    auto entropy_code = [&](int k) -> int {                  // chunk k is back in its pinned slot
-        const int sl = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
-        JA_HIP(ctx, hipEventSynchronize(ready[sl]));
-        std::vector<int> status((size_t)m, JPEG_AMD_OK);
-        auto work = [&](int t) {
-            for (int i = t; i < m; i += nthreads) {
-                const int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
-                for (int c = 0; c < nc; ++c) planes[c] = h_coef[sl][c] + plane[c] * i;
-                status[i] = jpeg_amd_jpeg_encode_spectral(frame, quanta_key, planes, h_quanta, h_quanta_keys, ntables, scans, nscans,
-                                                          metadata, nmetadata, h_out + (size_t)(base + i) * out_stride, out_stride,
-                                                          &nbytes[base + i]);
-            }
-        };
-        // a worker that cannot be started leaves its share to the calling thread (work does not throw)
-        std::vector<std::thread> pool;
-        int started = 1;
-        try {
-            pool.reserve((size_t)nthreads);
-            for (int t = 1; t < nthreads; ++t) { pool.emplace_back(work, t); ++started; }
-        } catch (...) {
+    const size_t piece = (size_t)4 << 20, per_image = (npx + piece - 1) / piece;   // pixels are staged in pieces of <= 4 MiB
+    // The device side of chunk k, asynchronous: pixels up and kernels on the context's stream, coefficients down on the
+    // second one, so that chunk k's download overlaps chunk k + 1's upload.  Device slot and pinned slot k & 1 were last
+    // used by chunk k - 2, whose download was waited for before its planes were entropy-coded.
+    auto submit = [&](int k) -> int {
+        const int slot = k & 1, m = std::min(chunk, n_images - k * chunk);
+        char *host = static_cast<char *>(ctx->file_pinned[slot]);
+        char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
+        int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+        for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<int16_t *>(dev + coef_off[c]);
+        JA_HIP(ctx, hipMemcpyAsync(dev, host, npx * m, hipMemcpyHostToDevice, ctx->stream));
+        JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, reinterpret_cast<const uint8_t *>(dev), npx, color, d_q, 0, ntables, d_coef, stride));
+        JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
+        JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
+        for (int c = 0; c < nc; ++c)
+            JA_HIP(ctx, hipMemcpyAsync(host + coef_off[c], dev + coef_off[c], plane[c] * 2 * m, hipMemcpyDeviceToHost, ctx->file_d2h));
+        JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->file_d2h));
+        return JPEG_AMD_OK;
+    };
+    // One parallel region of the host threads: the files of chunk `code` are written from its pinned planes (code >= 0, after
+    // its download) and the pixels of chunk `stage` are copied into its pinned slot (stage < nchunks).  The caller's pixels
+    // are pageable memory: copying them to pinned memory on all threads and uploading from there is what keeps the upload
+    // asynchronous and at the speed of the link.
+    auto host_region = [&](int code, int stage) -> int {
+        int m_code = 0, m_stage = 0;
+        const char *planes_host = nullptr;
+        char *stage_host = nullptr;
+        if (code >= 0) {
+            m_code = std::min(chunk, n_images - code * chunk);
+            JA_HIP(ctx, hipEventSynchronize(ctx->file_done[code & 1]));
+            planes_host = static_cast<const char *>(ctx->file_pinned[code & 1]);
         }
-        for (int t = started; t < nthreads; ++t) work(t);
-        work(0);
-        for (std::thread &th : pool) th.join();
+        if (stage < nchunks) {
+            m_stage = std::min(chunk, n_images - stage * chunk);
+            stage_host = static_cast<char *>(ctx->file_pinned[stage & 1]);   // (its last upload, chunk stage - 2, is long complete)
+        }
+        std::vector<int> status((size_t)std::max(m_code, 1), JPEG_AMD_OK);
+        const int copies = (int)(per_image * (size_t)m_stage);
+        run_parallel(nthreads, m_code + copies, [&](int j) {
+            if (j < m_code) {
+                const int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
+                for (int c = 0; c < nc; ++c) planes[c] = reinterpret_cast<const int16_t *>(planes_host + coef_off[c]) + plane[c] * j;
+                const size_t image = (size_t)code * chunk + (size_t)j;
+                status[(size_t)j] = jpeg_amd_jpeg_encode_spectral(frame, quanta_key, planes, h_quanta, h_quanta_keys, ntables, scans, nscans,
+                                                                  metadata, nmetadata, h_out + image * out_stride, out_stride, &nbytes[image]);
+            } else {
+                const size_t q = (size_t)(j - m_code), i = q / per_image, lo = (q % per_image) * piece, len = std::min(piece, npx - lo);
+                std::memcpy(stage_host + npx * i + lo, h_pixels + ((size_t)stage * chunk + i) * pixel_stride + lo, len);
+            }
+        });
         for (int st : status) if (st != JPEG_AMD_OK) return st;   // EINVAL with nbytes[i] > out_stride: buffer too small
         return JPEG_AMD_OK;
     };
-    for (int k = 0; k < nchunks; ++k) {
-        const int sl = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
-        // device side of chunk k, asynchronous (slot sl was consumed by entropy_code(k - 2))
-        for (int i = 0; i < m; ++i)
-            JA_HIP(ctx, hipMemcpyAsync(d_px + npx * i, h_pixels + (size_t)(base + i) * pixel_stride, npx, hipMemcpyHostToDevice, ctx->stream));
-        JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, d_px, npx, color, d_q, 0, ntables, d_coef, stride));
-        for (int c = 0; c < nc; ++c)
-            JA_HIP(ctx, hipMemcpyAsync(h_coef[sl][c], d_coef[c], plane[c] * 2 * m, hipMemcpyDeviceToHost, ctx->stream));
-        JA_HIP(ctx, hipEventRecord(ready[sl], ctx->stream));
-        if (k >= 1) {
-            const int st = entropy_code(k - 1);               // ... while the host writes the files of chunk k - 1
-            if (st != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); return st; }
-        }
+    int result = host_region(-1, 0);
+    if (result == JPEG_AMD_OK) result = submit(0);
+    for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
+        result = host_region(k - 1, k + 1);                       // ... while the device works on chunk k
+        if (result == JPEG_AMD_OK && k + 1 < nchunks) result = submit(k + 1);
     }
-    JA_TRY(entropy_code(nchunks - 1));
-    return JPEG_AMD_OK;
+    if (result == JPEG_AMD_OK) result = host_region(nchunks - 1, nchunks);
+    if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->file_d2h); }
+    return result;
 }
 JA_NOTHROW_TAIL
 

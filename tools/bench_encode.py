@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the fused encode kernel (development aid):  python tools/bench_encode.py [--size 4096] [--reps 50]"""
+"""Time the fused encode kernel (development aid):  python tools/bench_encode.py [--size 4096] [--height H] [--reps 50]"""
 import argparse, ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,10 +7,10 @@ import jpeg_amd as J
 from jpeg_amd import _lib, synth
 
 ap = argparse.ArgumentParser(); ap.add_argument("--size", type=int, default=4096); ap.add_argument("--reps", type=int, default=50)
-ap.add_argument("--only", default="")
+ap.add_argument("--only", default=""); ap.add_argument("--height", type=int, default=0)
 args = ap.parse_args()
 ctx = J.Context(0); dev = ctx.torch_device; lib = _lib.lib()
-W = H = args.size
+W = args.size; H = args.height or args.size
 RING = 4
 q_np = np.stack([J.compression_quanta("luminance", 1.0), J.compression_quanta("chrominance", 1.0)])
 d_q = torch.from_numpy(q_np.view(np.int16)).to(dev)

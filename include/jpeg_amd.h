@@ -288,7 +288,9 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
 /* The same for n_images files of ONE frame geometry (a burst, the frames of an MJPEG stream):
  * `nthreads` host threads (<= 0: all cores) entropy-decode into pinned buffers, the device decodes
  * a chunk of images per launch.  h_pixels: image i at h_pixels + i * pixel_stride (0 = W*H*3).
- * This is the restart-interval / image-level parallelism of SURVEY.md 8f-1 on the host side. */
+ * This is the restart-interval / image-level parallelism of SURVEY.md 8f-1 on the host side.
+ * h_pixels may be pageable (downloaded into the context's pinned slots, copied out by the host threads) or page-locked
+ * (hipHostMalloc / hipHostRegister: downloaded straight into it). */
 int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[],
                               int n_images, int nthreads, int cosited, jpeg_amd_color color,
                               uint8_t *h_pixels, size_t pixel_stride, jpeg_amd_frame_info *info);

@@ -176,6 +176,20 @@ int ensure_file_staging(jpeg_amd_ctx *ctx, size_t slot_bytes)
     return JPEG_AMD_OK;
 }
 
+// Is [p, p + bytes) page-locked host memory (hipHostMalloc / hipHostRegister) that a copy engine reaches directly?  Then the
+// batch entry points move the caller's buffer itself instead of staging it through their own pinned slots.
+bool is_pinned_host(const void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return false;
+    const char *ends[2] = {static_cast<const char *>(p), static_cast<const char *>(p) + bytes - 1};
+    for (const char *q : ends) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // (unregistered memory: an error, cleared)
+        if (at.type != hipMemoryTypeHost || at.isManaged) return false;
+    }
+    return true;
+}
+
 // fn(i) for i in [0, m) on up to `nthreads` threads; the calling thread takes a share, and the share of a worker that
 // cannot be started as well (fn does not throw)
 template <class F>
@@ -960,9 +974,12 @@ try {
 
     const int nchunks = (n_images + chunk - 1) / chunk;
     int result = JPEG_AMD_OK;
+    // a caller whose pixel buffer is page-locked gets the download straight into it: no copy out of the pinned slot
+    const bool direct_out = is_pinned_host(h_pixels, (size_t)(n_images - 1) * pixel_stride + npx);
     auto drain = [&](int k) -> int {                         // chunk k is on its way back: copy it out
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
         JA_HIP(ctx, hipEventSynchronize(ctx->file_done[slot]));
+        if (direct_out) return JPEG_AMD_OK;
         const uint8_t *src = static_cast<const uint8_t *>(ctx->file_pinned[slot]) + px_off;
         // copy out in pieces of <= 8 MiB so that one huge image is shared by the threads too
         const size_t piece = (size_t)8 << 20, per_image = (npx + piece - 1) / piece;
@@ -1030,7 +1047,11 @@ try {
                                          JPEG_AMD_MAX_PLANES, cosited, color, reinterpret_cast<uint8_t *>(dev + px_off), npx));
             JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
             JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
-            JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
+            if (!direct_out) JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
+            else if (pixel_stride == npx) JA_HIP(ctx, hipMemcpyAsync(h_pixels + (size_t)base * npx, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
+            else
+                for (int i = 0; i < m; ++i)
+                    JA_HIP(ctx, hipMemcpyAsync(h_pixels + (size_t)(base + i) * pixel_stride, dev + px_off + npx * i, npx, hipMemcpyDeviceToHost, ctx->file_d2h));
             JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->file_d2h));
             return JPEG_AMD_OK;
         };
@@ -1148,6 +1169,8 @@ try {
     JA_TRY(ensure_file_staging(ctx, slot_bytes));
 
     const int nchunks = (n_images + chunk - 1) / chunk;
+    // a caller whose pixels are page-locked gets them uploaded from where they are: nothing to stage
+    const bool direct_in = is_pinned_host(h_pixels, (size_t)(n_images - 1) * pixel_stride + npx);
     const size_t piece = (size_t)4 << 20, per_image = (npx + piece - 1) / piece;   // pixels are staged in pieces of <= 4 MiB
     // The device side of chunk k, asynchronous: pixels up and kernels on the context's stream, coefficients down on the
     // second one, so that chunk k's download overlaps chunk k + 1's upload.  Device slot and pinned slot k & 1 were last
@@ -1158,7 +1181,11 @@ try {
         char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
         int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
         for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<int16_t *>(dev + coef_off[c]);
-        JA_HIP(ctx, hipMemcpyAsync(dev, host, npx * m, hipMemcpyHostToDevice, ctx->stream));
+        if (!direct_in) JA_HIP(ctx, hipMemcpyAsync(dev, host, npx * m, hipMemcpyHostToDevice, ctx->stream));
+        else if (pixel_stride == npx) JA_HIP(ctx, hipMemcpyAsync(dev, h_pixels + (size_t)k * chunk * npx, npx * m, hipMemcpyHostToDevice, ctx->stream));
+        else
+            for (int i = 0; i < m; ++i)
+                JA_HIP(ctx, hipMemcpyAsync(dev + npx * i, h_pixels + ((size_t)k * chunk + i) * pixel_stride, npx, hipMemcpyHostToDevice, ctx->stream));
         JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, reinterpret_cast<const uint8_t *>(dev), npx, color, d_q, 0, ntables, d_coef, stride));
         JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
         JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
@@ -1180,7 +1207,7 @@ try {
             JA_HIP(ctx, hipEventSynchronize(ctx->file_done[code & 1]));
             planes_host = static_cast<const char *>(ctx->file_pinned[code & 1]);
         }
-        if (stage < nchunks) {
+        if (stage < nchunks && !direct_in) {
             m_stage = std::min(chunk, n_images - stage * chunk);
             stage_host = static_cast<char *>(ctx->file_pinned[stage & 1]);   // (its last upload, chunk stage - 2, is long complete)
         }

@@ -151,3 +151,51 @@ def test_twelve_bit_four_component_compress_reproduces_the_references_file(ctx):
         assert got.shape == w.shape and (got == w).all()
     out = rect.compress(qd, scans, process="progressive", metadata=metadata)
     assert bytes(out) == data.tobytes()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_compress_batch_over_several_chunks_pageable_and_pinned_pixels(ctx, pinned):
+    """70 pictures = three chunks of the pipeline; the pixels either in pageable memory (staged through the library's pinned
+    slots by the host threads) or page-locked (uploaded from where they are), with a pitch between the pictures; picture i
+    is the example picture with its first bytes changed, so that a chunk or slot mix-up cannot go unnoticed."""
+    import torch
+    import jpeg_amd as J
+    case = next(c for c in G.encode_cases() if c["mode"] == "4-2-0" and c["level"] == 0.5)
+    rgb, (w, h) = G.encode_source()
+    n = 70
+    stride = w * h * 3 + 32
+    holder = torch.zeros(n * stride, dtype=torch.uint8, pin_memory=pinned)
+    px = holder.numpy()
+    for i in range(n):
+        px[i * stride:i * stride + w * h * 3] = rgb.reshape(-1)
+        px[i * stride:i * stride + 24] = (i * 3) & 255
+    info = _lib.FrameInfo()
+    info.width, info.height, info.precision, info.ncomponents, info.process = w, h, 8, 3, 0
+    for c, (fx, fy) in enumerate(case["factors"]):
+        info.id[c], info.factor_x[c], info.factor_y[c] = c + 1, fx, fy
+    tables = _quanta(case["level"])
+    qkey, tk = (C.c_int32 * 3)(0, 1, 1), (C.c_int32 * 2)(0, 1)
+    sarr = _scan_array(SCANS)
+    marr, nmeta, _keep = _metadata_array(JFIF)
+    cap = 1 << 18
+    lib = _lib.lib()
+    want = {}
+    for threads in (1, 6):
+        out = np.zeros((n, cap), np.uint8)
+        sizes = (C.c_size_t * n)()
+        st = lib.jpeg_amd_compress_batch(ctx.handle, C.byref(info), px.ctypes.data, stride, n, J.RGB.code, qkey, tables.ctypes.data,
+                                         tk, 2, sarr, 2, marr, nmeta, threads, out.ctypes.data, cap, sizes)
+        assert st == 0, st
+        for i in range(n):
+            got = out[i, :sizes[i]].tobytes()
+            if i not in want:      # the single-picture entry point on the same pixels
+                one = np.zeros(cap, np.uint8)
+                nb = C.c_size_t()
+                f1 = _lib.FrameInfo()
+                C.memmove(C.byref(f1), C.byref(info), C.sizeof(f1))
+                st = lib.jpeg_amd_compress_batch(ctx.handle, C.byref(f1), px[i * stride:].ctypes.data, 0, 1, J.RGB.code, qkey,
+                                                 tables.ctypes.data, tk, 2, sarr, 2, marr, nmeta, 1, one.ctypes.data, cap, C.byref(nb))
+                assert st == 0, st
+                want[i] = one[:nb.value].tobytes()
+            assert got == want[i], (i, threads)
+    assert len(set(want.values())) > 40     # the pictures do differ

@@ -152,3 +152,31 @@ def test_twelve_bit_four_component_file_through_the_staged_path(ctx):
     rect = planar.interleaved(cosite=False).host_values()
     assert (rect == O.interleave(want, factors, spectral.layout.scale, spectral.size)).all()
     assert rect.max() > 255          # really more than 8 bits
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_decompress_batch_over_several_chunks_pageable_and_pinned_output(ctx, pinned):
+    """70 files = three chunks of the pipeline (both pinned / device slots are reused); the output either in pageable memory
+    (downloaded into the library's pinned slot and copied out by the host threads) or page-locked (downloaded straight into
+    the caller's buffer), with a row pitch between the images."""
+    import torch
+    import jpeg_amd as J
+    lib = _lib.lib()
+    names = ["color-sequential-1.jpg", "color-progressive-1.jpg", "color-sequential-restart.jpg"]
+    names = [n for n in names if (G.entry(n)["width"], G.entry(n)["height"]) == (G.entry(names[0])["width"], G.entry(names[0])["height"])]
+    files = [np.fromfile(G.path(G.entry(n)["file"]), np.uint8) for n in names]
+    n = 70
+    batch = [files[i % len(files)] for i in range(n)]
+    w, h = G.entry(names[0])["width"], G.entry(names[0])["height"]
+    stride = w * h * 3 + 64
+    holder = torch.zeros(n * stride, dtype=torch.uint8, pin_memory=pinned)
+    out = holder.numpy()
+    ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in batch])
+    sizes = (C.c_size_t * n)(*[f.size for f in batch])
+    for threads in (1, 5):
+        out[:] = 0
+        st = lib.jpeg_amd_decompress_batch(ctx.handle, ptrs, sizes, n, threads, 0, J.RGB.code, out.ctypes.data, stride, None)
+        assert st == 0, st
+        for i in range(n):
+            assert G.sha(out[i * stride:i * stride + w * h * 3]) == G.entry(names[i % len(names)])["gold"]["rgb_sha256"], (i, threads)
+            assert not out[i * stride + w * h * 3:(i + 1) * stride].any()

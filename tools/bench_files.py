@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import jpeg_amd as J
 from jpeg_amd import _lib
-ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=256); ap.add_argument("--threads", type=int, nargs="*", default=[1, 8, 32, 64])
+ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=256); ap.add_argument("--threads", type=int, nargs="*", default=[1, 8, 32, 64]); ap.add_argument("--pinned", action="store_true", help="the caller's pixel buffers are page-locked: no staging copy")
 args = ap.parse_args()
 ctx = J.Context(0); lib = _lib.lib()
 W, H = 1920, 1080
@@ -26,9 +26,9 @@ for i in range(8):   # 8 distinct frames, cycled
 n = args.n
 batch = [files[i % 8] for i in range(n)]
 ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in batch]); sizes = (C.c_size_t * n)(*[f.size for f in batch])
-out = np.zeros((n, W * H * 3), np.uint8)
+out_holder = torch.zeros((n, W * H * 3), dtype=torch.uint8, pin_memory=args.pinned); out = out_holder.numpy()
 mb = sum(f.size for f in batch) / 1e6
-print(f"{n} files of {W}x{H}, {mb/n*1e3:.0f} KB each")
+print(f"{n} files of {W}x{H}, {mb/n*1e3:.0f} KB each" + (", the caller's pixel buffers page-locked" if args.pinned else ""))
 for t in args.threads:
     for rep in range(2):
         t0 = time.perf_counter()
@@ -48,7 +48,7 @@ print(f"host entropy decode alone: {dt*1e3:.2f} ms per file on one thread = {W*H
 # the other direction: RGB bytes in host memory -> baseline JPEG bytes in host memory
 from jpeg_amd.api import _scan_array, _metadata_array
 n = min(args.n, 256)
-px = np.ascontiguousarray(np.tile(rgb.reshape(1, -1), (n, 1)))
+px_holder = torch.zeros((n, W * H * 3), dtype=torch.uint8, pin_memory=args.pinned); px = px_holder.numpy(); px[:] = rgb.reshape(1, -1)
 info = _lib.FrameInfo()
 info.width, info.height, info.precision, info.ncomponents, info.process = W, H, 8, 3, 0
 for c, (fx, fy) in enumerate([(2, 2), (1, 1), (1, 1)]):

@@ -272,6 +272,18 @@ int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *h_jpeg, size_t nbytes, 
  * Because it owns the planes it refuses frames of more than 32 Mi blocks in all (ENOMEM; larger frames go through
  * the one-shot entry points, where the caller allocates), and its first error is final: every later push returns
  * the same status without touching the decoder's state. */
+/* The same file as SPARSE coefficients: one 32-bit entry per nonzero coefficient (every block's DC has one) --
+ * bits 0-15 the int16 coefficient, bits 16-21 its zigzag index, bit 31 set on the last entry of its block -- the entries of a
+ * block in a row, and per block of the frame (planes in frame order, plane c's block (x, y) at
+ * sum(units_x * units_y of the planes before c) + y * units_x + x) the index of its first entry in h_desc, 0xFFFFFFFF for a
+ * block no scan reached.  What the host has to write and PCIe has to carry is an eighth of the planes for a typical file;
+ * jpeg_amd_spectral_expand rebuilds the planes on the device.  Sequential files with every restart marker in place only:
+ * JPEG_AMD_ENOSUP for anything else (progressive, a damaged marker sequence) and when `capacity` entries do not suffice --
+ * decode those with jpeg_amd_jpeg_decode_spectral. */
+int jpeg_amd_jpeg_decode_sparse(const uint8_t *data, size_t nbytes, uint32_t *h_desc, size_t ndesc,
+                                uint32_t *h_entries, size_t capacity, size_t *nentries,
+                                uint16_t h_quanta[][64], jpeg_amd_frame_info *info);
+
 typedef struct jpeg_amd_stream jpeg_amd_stream;
 jpeg_amd_stream *jpeg_amd_stream_create(void);
 void jpeg_amd_stream_destroy(jpeg_amd_stream *stream);

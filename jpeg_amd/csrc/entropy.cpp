@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
@@ -328,7 +329,22 @@ struct Component {
     int ux = 0, uy = 0;
     int16_t *coef = nullptr;
     bool bound = false;
+    size_t first_block = 0;   // sparse output: index of the plane's block (0, 0) in the descriptor array
 };
+
+// Sparse output of a sequential file (jpeg_amd_jpeg_decode_sparse): instead of int16 planes -- 128 bytes per block, of which a
+// typical file fills three or four coefficients -- one 32-bit ENTRY per nonzero coefficient (the DC always has one), the
+// entries of a block in a row, and per block the index of its first entry.  An eighth of the bytes to write on the host and
+// to move across PCIe; k_expand_sparse (kernels_stage.hip) turns it into the planes on the device.
+//   entry: bits 0-15 the coefficient, bits 16-21 its zigzag index, bit 31 the block's last entry
+//   descriptor: index of the block's first entry; kSparseAbsent = no scan reached the block (all zero)
+struct SparseOut {
+    uint32_t *desc = nullptr;
+    uint32_t *entries = nullptr;
+    size_t capacity = 0, n = 0;
+};
+constexpr uint32_t kSparseAbsent = 0xffffffffu, kSparseLast = 0x80000000u;
+int16_t g_sparse_sentinel[1];   // what Component::coef points at in a sparse decode (never dereferenced)
 
 struct Decoder {
     const uint8_t *data;
@@ -342,6 +358,7 @@ struct Decoder {
     int nthreads = 1;            // host threads for restart-interval-parallel scans
     bool auto_threads = false;   // nthreads chosen by the library: only where a thread pays off
     int max_scans = 0x7fffffff;  // stop after this many scans (progressive previews, JPEG.Context-style)
+    SparseOut *sparse = nullptr; // entries instead of planes (sequential scans with every restart marker in place only)
     int nscans = 0;
 
     static int units(int size, int stride) { return size / stride + (size % stride != 0 ? 1 : 0); }
@@ -450,9 +467,12 @@ struct Decoder {
             if (comps[c].fy > sy) sy = comps[c].fy;
         }
         info.scale_x = sx; info.scale_y = sy;
+        size_t blocks_before = 0;
         for (int c = 0; c < nc; ++c) {
             comps[c].ux = units(info.width * comps[c].fx, 8 * sx);
             comps[c].uy = units(info.height * comps[c].fy, 8 * sy);
+            comps[c].first_block = blocks_before;
+            blocks_before += (size_t)comps[c].ux * comps[c].uy;
             info.id[c] = comps[c].id;
             info.factor_x[c] = comps[c].fx; info.factor_y[c] = comps[c].fy;
             info.units_x[c] = comps[c].ux;  info.units_y[c] = comps[c].uy;
@@ -659,6 +679,7 @@ struct Decoder {
         // bytes [b, e), on a copy without stuffing.  A block is decoded into a local buffer (zero, then its few coefficients)
         // and copied out whole, so the plane is written once, front to back, and never read.
         const bool fast_sequential = !progressive && max_scans == 0x7fffffff;
+        if (sparse && !fast_sequential) return JPEG_AMD_ENOSUP;
         std::vector<uint64_t> pair_tables;
         std::vector<uint32_t> dc_tables;
         const uint64_t *pair_of[16];
@@ -684,6 +705,7 @@ struct Decoder {
             long mcu = 0, mcu1 = 0;
             int mx = 0, my = 0, si = 0;
             bool streaming = false;
+            uint32_t *ent = nullptr, *ent_end = nullptr;   // sparse output: the next entry, the end of the arena
             alignas(64) int16_t tmp[128];      // [64, 128): where the stores of a damaged stream land that run past the block
         };
         auto begin_walk = [&](Walk &w, const uint8_t *b, const uint8_t *e, long mcu0, long mcu1, std::vector<uint8_t> &scratch) {
@@ -702,7 +724,12 @@ struct Decoder {
             w.si = 0;
         };
         // the next block of a walk (slot w.si of MCU w.mcu)
-        auto next_block = [&](Walk &w) __attribute__((always_inline)) -> int {
+        auto next_block = [&](Walk &w, auto sparse_kind) __attribute__((always_inline)) -> int {
+            constexpr bool SPARSE = decltype(sparse_kind)::value;
+            uint32_t *const ent0 = w.ent;
+            if constexpr (SPARSE) {
+                if (w.ent + 72 > w.ent_end) return JPEG_AMD_ENOSUP;      // the arena is full: the caller decodes this file densely
+            }
             const Slot &sl = slots[w.si];
             Component *c = sl.c;
             const int x = ns > 1 ? w.mx * c->fx + sl.bx : w.mx, y = ns > 1 ? w.my * c->fy + sl.by : w.my;
@@ -722,12 +749,13 @@ struct Decoder {
                 if (t > 16) return JPEG_AMD_EINVAL;
                 if (t) w.pred[ci] += w.br.magnitude(t);
             }
-            w.tmp[0] = (int16_t)w.pred[ci];
+            if constexpr (SPARSE) *w.ent++ = (uint32_t)(uint16_t)(int16_t)w.pred[ci];
+            else w.tmp[0] = (int16_t)w.pred[ci];
             // ---- AC (T.81 F.2.2.2) ----
+            int k = 1;
             if (!done) {
                 const Huffman &h = ac[sl.ta];
                 const uint64_t *chains = pair_of[w.si];
-                int k = 1;
                 while (k < 64) {
                     if (budget < kChainBits) { w.br.refill(); budget = 56; }
                     uint64_t en = chains[w.br.acc >> (64 - kChainBits)];
@@ -750,20 +778,46 @@ struct Decoder {
                             continue;
                         }
                         k += r;
-                        w.tmp[k] = (int16_t)w.br.magnitude(sz);       // k <= 63 + 15
+                        if constexpr (SPARSE) *w.ent++ = (uint32_t)k << 16 | (uint16_t)(int16_t)w.br.magnitude(sz);
+                        else w.tmp[k] = (int16_t)w.br.magnitude(sz);  // k <= 63 + 15
                         ++k;
                         continue;
                     }
                     w.br.skip(n);
                     budget -= n;
-                    w.tmp[k + ((en >> 4) & 127)] = (int16_t)(en >> 32);
-                    w.tmp[k + ((en >> 11) & 127)] = (int16_t)(en >> 48);
+                    if constexpr (SPARSE) {
+                        // the entry's two stores: both written, the cursor advanced by the number that are real (a
+                        // coefficient is never zero; an entry without one has value 0, one with a single one repeats it)
+                        const uint32_t a1 = (uint32_t)(en >> 4) & 127, a2 = (uint32_t)(en >> 11) & 127;
+                        const uint32_t v1 = (uint32_t)(en >> 32) & 0xffffu, v2 = (uint32_t)(en >> 48);
+                        w.ent[0] = ((uint32_t)k + a1) << 16 | v1;
+                        w.ent[1] = ((uint32_t)k + a2) << 16 | v2;
+                        w.ent += (v1 != 0) + (a1 != a2);
+                    } else {
+                        w.tmp[k + ((en >> 4) & 127)] = (int16_t)(en >> 32);
+                        w.tmp[k + ((en >> 11) & 127)] = (int16_t)(en >> 48);
+                    }
                     k += (int)(en >> 18) & 127;
                     if (en & (1ull << 25)) break;
                 }
             }
-            if (x < c->ux && y < c->uy) store_block(c->coef + (size_t)64 * ((size_t)c->ux * y + x), w.tmp, w.streaming);
-            std::memset(w.tmp, 0, 128);
+            if constexpr (SPARSE) {
+                if (x < c->ux && y < c->uy) {
+                    if (__builtin_expect(k > 64, 0)) {                   // a damaged stream ran past the block: drop what lies beyond
+                        uint32_t *keep = ent0;
+                        for (const uint32_t *q = ent0; q < w.ent; ++q)
+                            if ((*q >> 16) < 64) *keep++ = *q;
+                        w.ent = keep;                                    // (the DC entry is always kept)
+                    }
+                    w.ent[-1] |= kSparseLast;
+                    sparse->desc[c->first_block + (size_t)c->ux * y + x] = (uint32_t)(ent0 - sparse->entries);
+                } else {
+                    w.ent = ent0;                                        // decoded and dropped (decode.swift:1459-1475)
+                }
+            } else {
+                if (x < c->ux && y < c->uy) store_block(c->coef + (size_t)64 * ((size_t)c->ux * y + x), w.tmp, w.streaming);
+                std::memset(w.tmp, 0, 128);
+            }
             if (++w.si == nslots) {
                 w.si = 0;
                 ++w.mcu;
@@ -781,8 +835,18 @@ struct Decoder {
         auto seq_interval = [&](const uint8_t *b, const uint8_t *e, long mcu0, long mcu1, std::vector<uint8_t> &scratch) -> int {
             Walk w;
             begin_walk(w, b, e, mcu0, mcu1, scratch);
+            if (sparse) {                                                // (one interval after the other: the arena is shared)
+                w.ent = sparse->entries + sparse->n;
+                w.ent_end = sparse->entries + sparse->capacity;
+                while (w.mcu < w.mcu1) {
+                    const int st = next_block(w, std::true_type{});
+                    if (st != JPEG_AMD_OK) return st;
+                }
+                sparse->n = (size_t)(w.ent - sparse->entries);
+                return JPEG_AMD_OK;
+            }
             while (w.mcu < w.mcu1) {
-                const int st = next_block(w);
+                const int st = next_block(w, std::false_type{});
                 if (st != JPEG_AMD_OK) return st;
             }
             end_walk(w);
@@ -840,6 +904,7 @@ struct Decoder {
                 return JPEG_AMD_OK;
             }
         }
+        if (sparse) return JPEG_AMD_ENOSUP;          // a restart marker is missing: the resynchronising reader writes planes
         BitReader br(ecs, end);
         for (long k = 0; k < nintervals; ++k) {
             if (k) br.restart();
@@ -915,7 +980,10 @@ struct Decoder {
                         }
                     } else if (st == JPEG_AMD_OK) {
                         have_frame = true;
-                        if (coef)
+                        if (sparse) {
+                            if (info.process == 2) return JPEG_AMD_ENOSUP;      // progressive scans add to a block: planes only
+                            for (int c = 0; c < info.ncomponents; ++c) comps[c].coef = g_sparse_sentinel;
+                        } else if (coef)
                             for (int c = 0; c < info.ncomponents; ++c) {
                                 if (!coef[c]) return JPEG_AMD_EINVAL;
                                 comps[c].coef = coef[c];
@@ -1042,6 +1110,35 @@ int jpeg_amd_jpeg_decode_spectral_partial(const uint8_t *data, size_t nbytes, in
     if (st != JPEG_AMD_OK) return st;
     for (const Component &c : d.comps)
         if (!c.bound && max_scans == 0) return JPEG_AMD_EINVAL;   // a component no scan ever touched
+    if (info) *info = d.info;
+    return JPEG_AMD_OK;
+    JA_NOTHROW_END
+}
+
+int jpeg_amd_jpeg_decode_sparse(const uint8_t *data, size_t nbytes, uint32_t *h_desc, size_t ndesc, uint32_t *h_entries,
+                                size_t capacity, size_t *nentries, uint16_t h_quanta[][64], jpeg_amd_frame_info *info)
+{
+    if (!data || !h_desc || !h_entries || !nentries || !h_quanta) return JPEG_AMD_EINVAL;
+    JA_NOTHROW_BEGIN
+    {   // the descriptor array must hold every block of the frame
+        Decoder probe{data, nbytes};
+        const int st = probe.run(nullptr, nullptr);
+        if (st != JPEG_AMD_OK) return st;
+        size_t blocks = 0;
+        for (const Component &c : probe.comps) blocks += (size_t)c.ux * c.uy;
+        if (blocks > ndesc || blocks >= kSparseAbsent) return JPEG_AMD_EINVAL;
+        std::memset(h_desc, 0xff, blocks * sizeof(uint32_t));
+    }
+    SparseOut out;
+    out.desc = h_desc; out.entries = h_entries; out.capacity = capacity;
+    Decoder d{data, nbytes};
+    d.nthreads = 1;
+    d.sparse = &out;
+    const int st = d.run(nullptr, h_quanta);
+    if (st != JPEG_AMD_OK) return st;
+    for (const Component &c : d.comps)
+        if (!c.bound) return JPEG_AMD_EINVAL;   // a component no scan ever touched
+    *nentries = out.n;
     if (info) *info = d.info;
     return JPEG_AMD_OK;
     JA_NOTHROW_END

@@ -153,3 +153,34 @@ def test_parallel_decoder_falls_back_when_a_restart_marker_is_missing():
     a = lib.jpeg_amd_jpeg_decode_spectral_mt(buf.ctypes.data, buf.size, _lib.ptr_array([p.ctypes.data for p in planes]), q.ctypes.data, None, 4)
     b = lib.jpeg_amd_jpeg_decode_spectral(buf.ctypes.data, buf.size, _lib.ptr_array([p.ctypes.data for p in planes]), q.ctypes.data, None)
     assert a == b                                    # same verdict as the sequential decoder, no crash
+
+
+from _sparse import sparse_decode as _sparse, expand as _expand
+
+
+@pytest.mark.parametrize("name", G.decode_names())
+def test_sparse_decode_expands_to_the_planes(name):
+    """jpeg_amd_jpeg_decode_sparse: one entry per nonzero coefficient + one descriptor per block; expanded, they are the planes
+    of jpeg_amd_jpeg_decode_spectral.  Progressive files are refused (ENOSUP: planes only)."""
+    lib = _lib.lib()
+    e = G.entry(name)
+    data = open(G.path(e["file"]), "rb").read()
+    info = _lib.FrameInfo()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    assert lib.jpeg_amd_jpeg_inspect(buf, len(data), C.byref(info)) == 0
+    st, desc, ent, quanta = _sparse(lib, data, info)
+    if info.process == 2:
+        assert st == _lib.ENOSUP
+        return
+    assert st == 0, st
+    planes = [np.zeros((info.units_y[c], info.units_x[c], 64), np.int16) for c in range(info.ncomponents)]
+    q2 = np.zeros((4, 64), np.uint16)
+    assert lib.jpeg_amd_jpeg_decode_spectral(buf, len(data), _lib.ptr_array([p.ctypes.data for p in planes]), q2.ctypes.data, None) == 0
+    for a, b in zip(_expand(info, desc, ent), planes):
+        assert (a == b).all()
+    assert (quanta == q2).all()
+    nonzero = sum(int((p[..., 1:] != 0).sum()) + p.shape[0] * p.shape[1] for p in planes)   # every DC + the nonzero ACs
+    assert ent.size == nonzero
+    # an arena that is too small is reported, not overrun
+    st, _, _, _ = _sparse(lib, data, info, capacity=max(1, ent.size // 2))
+    assert st == _lib.ENOSUP

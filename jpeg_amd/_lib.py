@@ -85,6 +85,7 @@ SIGNATURES = {
     "jpeg_amd_jpeg_decode_spectral": (C.c_int, [_p, C.c_size_t, _pp, _p, _p]),
     "jpeg_amd_jpeg_decode_spectral_mt": (C.c_int, [_p, C.c_size_t, _pp, _p, _p, C.c_int]),
     "jpeg_amd_jpeg_decode_spectral_partial": (C.c_int, [_p, C.c_size_t, _pp, _p, _p, C.c_int, C.c_int]),
+    "jpeg_amd_spectral_expand_batch": (C.c_int, [_p, _L, C.c_int, _p, C.c_size_t, _p, C.c_size_t, _p, _pp, _szp]),
     "jpeg_amd_jpeg_decode_sparse": (C.c_int, [_p, C.c_size_t, _p, C.c_size_t, _p, C.c_size_t, _p, _p, _p]),
     "jpeg_amd_stream_create": (C.c_void_p, []),
     "jpeg_amd_stream_destroy": (None, [_p]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     "jpeg_amd_stream_snapshot": (C.c_int, [_p, _pp, _p]),
     "jpeg_amd_decompress": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_decompress_batch": (C.c_int, [_p, _pp, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_size_t, _p]),
+    "jpeg_amd_decompress_batch_device": (C.c_int, [_p, _pp, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_jpeg_encode_spectral": (C.c_int, [_p, _p, _pp, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_compress": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_compress_batch": (C.c_int, [_p, _p, _p, C.c_size_t, C.c_int, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int,

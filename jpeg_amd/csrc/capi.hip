@@ -9,6 +9,10 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <chrono>
 #include <system_error>
 #include <thread>
@@ -189,6 +193,85 @@ bool is_pinned_host(const void *p, size_t bytes)
     }
     return true;
 }
+
+// The host threads of one batch call, started once and handed one parallel region after the other (a chunk of files to
+// decode, a chunk of planes to entropy-code): starting 32 threads costs more than half of what a chunk of 32 1080p files
+// takes them.  Items are drawn from a counter (files differ in length); the calling thread works too.  Not re-entrant:
+// one region at a time.
+class WorkerPool {
+public:
+    explicit WorkerPool(int nthreads)
+    {
+        try {
+            threads_.reserve((size_t)std::max(0, nthreads - 1));
+            for (int t = 1; t < nthreads; ++t) threads_.emplace_back([this] { work(); });
+        } catch (...) {      // fewer threads than asked for: the ones that did start (and the caller) do the work
+        }
+    }
+    ~WorkerPool()
+    {
+        finish();
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        go_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
+    // fn(i) for i in [0, count); fn does not throw.  begin() hands the region to the workers and returns; finish() has the
+    // calling thread take its share and waits for the rest.
+    void begin(int count, std::function<void(int)> fn)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = std::move(fn); count_ = std::max(0, count); next_.store(0);
+            busy_ = (int)threads_.size();
+            ++generation_;
+            open_ = true;
+        }
+        go_.notify_all();
+    }
+    void finish()
+    {
+        if (!open_) return;
+        for (int i; (i = next_.fetch_add(1)) < count_;) job_(i);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return busy_ == 0; });
+        open_ = false;
+    }
+    void run(int count, std::function<void(int)> fn)
+    {
+        begin(count, std::move(fn));
+        finish();
+    }
+
+private:
+    void work()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            int count;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                go_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                count = count_;
+            }
+            for (int i; (i = next_.fetch_add(1)) < count;) job_(i);   // (job_ is not touched until every worker has reported back)
+            std::lock_guard<std::mutex> g(m_);
+            if (--busy_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable go_, done_;
+    std::function<void(int)> job_;
+    std::atomic<int> next_{0};
+    int count_ = 0, busy_ = 0;
+    bool open_ = false;
+    unsigned long generation_ = 0;
+    bool stop_ = false;
+};
 
 // fn(i) for i in [0, m) on up to `nthreads` threads; the calling thread takes a share, and the share of a worker that
 // cannot be started as well (fn does not throw)
@@ -508,6 +591,24 @@ int jpeg_amd_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const int16_t *
     const size_t zero[JPEG_AMD_MAX_PLANES] = {0, 0, 0, 0};
     return jpeg_amd_decode_batch(ctx, L, 1, d_coef, zero, d_q, 0, ntables, cosited, color,
                                  d_pixels, 0);
+}
+
+int jpeg_amd_spectral_expand_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_images, const uint32_t *d_desc,
+                                   size_t desc_stride, const uint32_t *d_entries, size_t entries_stride, const uint8_t *d_skip,
+                                   int16_t *const d_coef[], const size_t coef_stride[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, -1));
+    if (n_images < 0 || n_images > 65535) return JPEG_AMD_EINVAL;
+    if (n_images == 0) return JPEG_AMD_OK;
+    if (!d_desc || !d_entries || !d_coef || !coef_stride) return JPEG_AMD_EINVAL;
+    PlaneSetMut cs{};
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (!d_coef[p]) return JPEG_AMD_EINVAL;
+        cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p];
+    }
+    JA_HIP(ctx, launch_expand_sparse(ctx->stream, n_images, *L, d_desc, desc_stride, d_entries, entries_stride, d_skip, cs));
+    return JPEG_AMD_OK;
 }
 
 int jpeg_amd_spectral_rectangular_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_images,
@@ -929,14 +1030,18 @@ JA_NOTHROW_TAIL
 // ---- many JPEG files of one geometry -> pixels: host threads entropy-decode a chunk into
 //      pinned memory while the device (H2D, fused decode, D2H on the context's stream) works on
 //      the previous chunk ----------------------------------------------------------------------
-int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[],
-                              int n_images, int nthreads, int cosited, jpeg_amd_color color,
-                              uint8_t *h_pixels, size_t pixel_stride, jpeg_amd_frame_info *info_out)
-try {
+namespace {
+
+// Files -> pixels, in host memory (h_pixels) or left on the device (d_pixels_out): see jpeg_amd_decompress_batch[_device].
+int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[], int n_images, int nthreads,
+                          int cosited, jpeg_amd_color color, uint8_t *h_pixels, uint8_t *d_pixels_out, size_t pixel_stride,
+                          jpeg_amd_frame_info *info_out)
+{
     JA_TRY(bind(ctx));
-    if (!h_jpeg || !nbytes || !h_pixels || n_images < 0) return JPEG_AMD_EINVAL;
+    if (!h_jpeg || !nbytes || (!h_pixels && !d_pixels_out) || n_images < 0) return JPEG_AMD_EINVAL;
     if (n_images == 0) return JPEG_AMD_OK;
     if (!h_jpeg[0]) return JPEG_AMD_EINVAL;
+    const bool to_host = h_pixels != nullptr;
     jpeg_amd_frame_info fi;
     JA_TRY(jpeg_amd_jpeg_inspect(h_jpeg[0], nbytes[0], &fi));
     if (info_out) *info_out = fi;
@@ -952,34 +1057,42 @@ try {
     size_t plane[JPEG_AMD_MAX_PLANES] = {};
     size_t coef_off[JPEG_AMD_MAX_PLANES] = {};
     const int chunk = std::min(n_images, 32);
+    size_t blocks = 0;
     for (int c = 0; c < nc; ++c) {
         L.factor_x[c] = fi.factor_x[c]; L.factor_y[c] = fi.factor_y[c];
         L.units_x[c] = fi.units_x[c];   L.units_y[c] = fi.units_y[c];
         L.qi[c] = c;
         plane[c] = (size_t)64 * fi.units_x[c] * fi.units_y[c];
+        blocks += (size_t)fi.units_x[c] * fi.units_y[c];
     }
-    // slot layout: [coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk][quanta x chunk][pixels x chunk]
+    // Sequential files travel as SPARSE coefficients (jpeg_amd_jpeg_decode_sparse: a descriptor per block + an entry per
+    // nonzero coefficient, an eighth of the planes for a typical file) and are expanded on the device; an image that does not
+    // fit its arena, a progressive or a damaged one is decoded into planes as before and uploaded whole.
+    // Arena: 24 entries per block (3/4 of the planes' bytes at most; only what is used is uploaded).
+    const size_t arena = 24 * blocks, sparse_elems = blocks + arena;           // uint32 per image: [descriptors][entries]
+    // slot layout: [coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk][quanta x chunk][sparse x chunk][skip flags][pixels x chunk]
     size_t off = 0;
     for (int c = 0; c < nc; ++c) { coef_off[c] = off; off += align256(plane[c] * 2 * chunk); }
     const size_t quanta_off = off;  off += align256((size_t)chunk * kQSlotElems * 2);
-    const size_t px_off = off;      off += align256(npx * chunk);
+    const size_t sparse_off = off;  off += align256(sparse_elems * 4 * chunk);
+    const size_t skip_off = off;    off += align256((size_t)chunk);
+    const size_t px_off = off;      off += to_host ? align256(npx * chunk) : 0;
     const size_t slot_bytes = off;
     JA_TRY(ensure_file_staging(ctx, slot_bytes));
     const bool auto_threads = nthreads <= 0;
     if (auto_threads) nthreads = (int)std::thread::hardware_concurrency();
     nthreads = std::max(1, nthreads);
 
-
-    auto parallel = [&](int m, auto &&fn) { run_parallel(nthreads, m, fn); };
+    auto parallel = [&](int m, auto &&fn) { run_parallel(nthreads, m, fn); };   // (the copy out: on its own threads, beside the pool)
 
     const int nchunks = (n_images + chunk - 1) / chunk;
     int result = JPEG_AMD_OK;
     // a caller whose pixel buffer is page-locked gets the download straight into it: no copy out of the pinned slot
-    const bool direct_out = is_pinned_host(h_pixels, (size_t)(n_images - 1) * pixel_stride + npx);
+    const bool direct_out = to_host && is_pinned_host(h_pixels, (size_t)(n_images - 1) * pixel_stride + npx);
     auto drain = [&](int k) -> int {                         // chunk k is on its way back: copy it out
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
         JA_HIP(ctx, hipEventSynchronize(ctx->file_done[slot]));
-        if (direct_out) return JPEG_AMD_OK;
+        if (direct_out || !to_host) return JPEG_AMD_OK;
         const uint8_t *src = static_cast<const uint8_t *>(ctx->file_pinned[slot]) + px_off;
         // copy out in pieces of <= 8 MiB so that one huge image is shared by the threads too
         const size_t piece = (size_t)8 << 20, per_image = (npx + piece - 1) / piece;
@@ -992,41 +1105,101 @@ try {
     struct Joining { std::thread t; ~Joining() { if (t.joinable()) t.join(); } } drainer_owner;   // joined on every way out
     std::thread &drainer = drainer_owner.t;
     int drain_status = JPEG_AMD_OK;
+    std::vector<size_t> used_of[2] = {std::vector<size_t>((size_t)chunk, 0), std::vector<size_t>((size_t)chunk, 0)};   // per slot: entries of image i (sparse images)
+    std::vector<int> status_all((size_t)n_images, JPEG_AMD_OK);
+    // The entropy decoding: ONE queue of files for the whole call.  A host thread takes the next file, waits (rarely) until the
+    // pinned slot of the file's chunk is free, and decodes it there; this thread submits a chunk to the device as soon as its
+    // last file is in.  No barrier between chunks on the host threads' side: a thread that is done with its file of chunk k
+    // goes on with chunk k + 1 while a slower one still works on chunk k.
+    // Pinned slot k & 1 is free for chunk k once the kernels of chunk k - 2 are done (its uploads read the slot's coefficient,
+    // sparse and table regions; file_decoded[slot] is recorded behind them).  The helper thread that copies chunk k - 2's
+    // pixels out of the same slot may still be running; it only reads the pixel region, which the decoders do not touch.
+    struct Queue {
+        std::mutex m;
+        std::condition_variable cv;
+        int open_chunks;            // chunks [0, open_chunks) may be decoded
+        std::vector<int> left;      // files of chunk k not decoded yet
+        bool abort = false;
+    } queue;
+    queue.open_chunks = std::min(2, nchunks);
+    queue.left.resize((size_t)nchunks);
+    for (int k = 0; k < nchunks; ++k) queue.left[(size_t)k] = std::min(chunk, n_images - k * chunk);
+    std::atomic<int> next_file{0};
+    auto decode_file = [&](int file) -> int {
+        const int k = file / chunk, i = file - k * chunk, slot = k & 1, m = std::min(chunk, n_images - k * chunk);
+        char *host = static_cast<char *>(ctx->file_pinned[slot]);
+        uint8_t *skip = reinterpret_cast<uint8_t *>(host + skip_off);
+        // fewer files than threads: the spare threads go to the restart intervals of each file (planes: the sparse form
+        // is written by one thread per file)
+        const int inner = std::max(1, nthreads / m);
+        int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
+        for (int c = 0; c < nc; ++c) planes[c] = reinterpret_cast<int16_t *>(host + coef_off[c]) + plane[c] * i;
+        uint16_t(*quanta)[64] = reinterpret_cast<uint16_t(*)[64]>(host + quanta_off + (size_t)i * kQSlotElems * 2);
+        jpeg_amd_frame_info f{};
+        skip[i] = 1;
+        used_of[slot][(size_t)i] = 0;
+        if (!h_jpeg[file]) return JPEG_AMD_EINVAL;
+        // geometry first: the planes are sized for image 0
+        int st = jpeg_amd_jpeg_inspect(h_jpeg[file], nbytes[file], &f);
+        if (st == JPEG_AMD_OK) {
+            bool same = f.width == fi.width && f.height == fi.height && f.precision == 8 && f.ncomponents == nc;
+            for (int c = 0; same && c < nc; ++c)
+                same = f.factor_x[c] == fi.factor_x[c] && f.factor_y[c] == fi.factor_y[c];
+            if (!same) st = JPEG_AMD_EINVAL;                 // one geometry per batch
+        }
+        // (spare threads only help a file that has restart intervals; such a file is decoded into planes on `inner` threads)
+        if (st == JPEG_AMD_OK && (inner == 1 || f.restart_interval == 0) && f.process != 2) {
+            uint32_t *sp = reinterpret_cast<uint32_t *>(host + sparse_off) + sparse_elems * (size_t)i;
+            size_t n = 0;
+            const int ss = jpeg_amd_jpeg_decode_sparse(h_jpeg[file], nbytes[file], sp, blocks, sp + blocks, arena, &n, quanta, nullptr);
+            if (ss == JPEG_AMD_OK) { skip[i] = 0; used_of[slot][(size_t)i] = n; }
+            else if (ss != JPEG_AMD_ENOSUP) st = ss;
+        }
+        if (st == JPEG_AMD_OK && skip[i])
+            st = jpeg_amd_jpeg_decode_spectral_mt(h_jpeg[file], nbytes[file], planes, quanta, nullptr, inner > 1 && auto_threads ? 0 : inner);
+        return st;
+    };
+    auto worker = [&]() {
+        for (;;) {
+            const int file = next_file.fetch_add(1);
+            if (file >= n_images) return;
+            const int k = file / chunk;
+            {
+                std::unique_lock<std::mutex> g(queue.m);
+                queue.cv.wait(g, [&] { return queue.abort || queue.open_chunks > k; });
+                if (queue.abort) return;
+            }
+            int st;
+            try { st = decode_file(file); } catch (...) { st = JPEG_AMD_ENOMEM; }
+            status_all[(size_t)file] = st;
+            std::lock_guard<std::mutex> g(queue.m);
+            if (--queue.left[(size_t)k] == 0) queue.cv.notify_all();
+        }
+    };
+    struct Workers {      // joined on every way out, after telling them to stop
+        Queue &q; std::vector<std::thread> t;
+        ~Workers() { { std::lock_guard<std::mutex> g(q.m); q.abort = true; } q.cv.notify_all(); for (std::thread &x : t) x.join(); }
+    } workers{queue, {}};
+    {
+        const int t_n = std::min(nthreads, n_images);
+        try {
+            workers.t.reserve((size_t)t_n);
+            for (int t = 0; t < t_n; ++t) workers.t.emplace_back(worker);
+        } catch (...) {
+        }
+        if (workers.t.empty()) return JPEG_AMD_ENOMEM;      // not one thread to be had
+    }
     for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
         char *host = static_cast<char *>(ctx->file_pinned[slot]);
-        // Pinned slot `slot` was last used by chunk k - 2, whose uploads read its coefficient and table regions
-        // asynchronously: they are complete once that chunk's kernels are (file_decoded[slot] was recorded behind
-        // them).  The helper thread that copies chunk k - 2's pixels out of the same slot may still be running; it
-        // only reads the pixel region, which the decode below does not touch.
+        const uint8_t *skip = reinterpret_cast<const uint8_t *>(host + skip_off);
+        const size_t *used = used_of[slot].data();
         // (like every failure inside this loop it leaves through the common tail below, which waits for both streams)
-        if (k >= 2) {
-            const hipError_t w = hipEventSynchronize(ctx->file_decoded[slot]);
-            if (w != hipSuccess) { ctx->last_hip = (int)w; result = JPEG_AMD_EHIP; break; }
+        {
+            std::unique_lock<std::mutex> g(queue.m);
+            queue.cv.wait(g, [&] { return queue.left[(size_t)k] == 0; });          // chunk k is decoded
         }
-        std::vector<int> status((size_t)m, JPEG_AMD_OK);
-        parallel(m, [&](int i) {
-            int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
-            for (int c = 0; c < nc; ++c) planes[c] = reinterpret_cast<int16_t *>(host + coef_off[c]) + plane[c] * i;
-            jpeg_amd_frame_info f{};
-            if (!h_jpeg[base + i]) { status[i] = JPEG_AMD_EINVAL; return; }
-            // geometry first: the planes are sized for image 0
-            int st = jpeg_amd_jpeg_inspect(h_jpeg[base + i], nbytes[base + i], &f);
-            if (st == JPEG_AMD_OK) {
-                bool same = f.width == fi.width && f.height == fi.height && f.precision == 8 && f.ncomponents == nc;
-                for (int c = 0; same && c < nc; ++c)
-                    same = f.factor_x[c] == fi.factor_x[c] && f.factor_y[c] == fi.factor_y[c];
-                if (!same) st = JPEG_AMD_EINVAL;             // one geometry per batch
-            }
-            // fewer files than threads: the spare threads go to the restart intervals of each file
-            const int inner = std::max(1, nthreads / m);
-            if (st == JPEG_AMD_OK)
-                st = jpeg_amd_jpeg_decode_spectral_mt(h_jpeg[base + i], nbytes[base + i], planes,
-                        reinterpret_cast<uint16_t(*)[64]>(host + quanta_off + (size_t)i * kQSlotElems * 2), nullptr,
-                        inner > 1 && auto_threads ? 0 : inner);
-            status[i] = st;
-        });
-        for (int st : status) if (st != JPEG_AMD_OK) result = st;
+        for (int i = 0; i < m; ++i) if (status_all[(size_t)(base + i)] != JPEG_AMD_OK) result = status_all[(size_t)(base + i)];
         if (drainer.joinable()) { drainer.join(); if (drain_status != JPEG_AMD_OK) result = drain_status; }
         if (result != JPEG_AMD_OK) break;
         // the device side of chunk k (asynchronous); the host moves on to chunk k + 1 meanwhile.
@@ -1035,17 +1208,41 @@ try {
         // (a failure in here leaves copies and kernels in flight: no early return, the common tail below waits for both streams)
         auto submit = [&]() -> int {
             char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
-            const int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
-            for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<const int16_t *>(dev + coef_off[c]);
+            int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+            for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<int16_t *>(dev + coef_off[c]);
             size_t stride[JPEG_AMD_MAX_PLANES] = {};
-            for (int c = 0; c < nc; ++c) {
-                stride[c] = plane[c];
-                JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c], host + coef_off[c], plane[c] * 2 * m, hipMemcpyHostToDevice, ctx->stream));
+            for (int c = 0; c < nc; ++c) stride[c] = plane[c];
+            bool any_sparse = false, all_dense = true;
+            for (int i = 0; i < m; ++i) { any_sparse = any_sparse || !skip[i]; all_dense = all_dense && skip[i]; }
+            if (all_dense) {
+                for (int c = 0; c < nc; ++c)
+                    JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c], host + coef_off[c], plane[c] * 2 * m, hipMemcpyHostToDevice, ctx->stream));
+            } else {
+                for (int i = 0; i < m; ++i) {
+                    if (skip[i]) {                          // planes, this image only
+                        for (int c = 0; c < nc; ++c)
+                            JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c] + plane[c] * 2 * i, host + coef_off[c] + plane[c] * 2 * i, plane[c] * 2,
+                                                       hipMemcpyHostToDevice, ctx->stream));
+                    } else {                                // descriptors + the entries in use
+                        const size_t at = sparse_off + sparse_elems * 4 * (size_t)i;
+                        JA_HIP(ctx, hipMemcpyAsync(dev + at, host + at, (blocks + used[i]) * 4, hipMemcpyHostToDevice, ctx->stream));
+                    }
+                }
+                JA_HIP(ctx, hipMemcpyAsync(dev + skip_off, host + skip_off, (size_t)m, hipMemcpyHostToDevice, ctx->stream));
             }
             JA_HIP(ctx, hipMemcpyAsync(dev + quanta_off, host + quanta_off, (size_t)m * kQSlotElems * 2, hipMemcpyHostToDevice, ctx->stream));
+            if (any_sparse)
+                JA_TRY(jpeg_amd_spectral_expand_batch(ctx, &L, m, reinterpret_cast<const uint32_t *>(dev + sparse_off), sparse_elems,
+                                                      reinterpret_cast<const uint32_t *>(dev + sparse_off) + blocks, sparse_elems,
+                                                      reinterpret_cast<const uint8_t *>(dev + skip_off), d_coef, stride));
+            uint8_t *d_px = to_host ? reinterpret_cast<uint8_t *>(dev + px_off) : d_pixels_out + (size_t)base * pixel_stride;
             JA_TRY(jpeg_amd_decode_batch(ctx, &L, m, d_coef, stride, reinterpret_cast<const uint16_t *>(dev + quanta_off), kQSlotElems,
-                                         JPEG_AMD_MAX_PLANES, cosited, color, reinterpret_cast<uint8_t *>(dev + px_off), npx));
+                                         JPEG_AMD_MAX_PLANES, cosited, color, d_px, to_host ? npx : pixel_stride));
             JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
+            if (!to_host) {                                  // the pixels stay where they are: done when the kernels are
+                JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->stream));
+                return JPEG_AMD_OK;
+            }
             JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
             if (!direct_out) JA_HIP(ctx, hipMemcpyAsync(host + px_off, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
             else if (pixel_stride == npx) JA_HIP(ctx, hipMemcpyAsync(h_pixels + (size_t)base * npx, dev + px_off, npx * m, hipMemcpyDeviceToHost, ctx->file_d2h));
@@ -1068,12 +1265,40 @@ try {
                 if (drain_status != JPEG_AMD_OK) { result = drain_status; break; }
             }
         }
+        // chunk k + 1 goes into the pinned slot of chunk k - 1: free when that chunk's kernels are done
+        if (k >= 1 && k + 1 < nchunks) {
+            const hipError_t w = hipEventSynchronize(ctx->file_decoded[(k - 1) & 1]);
+            if (w != hipSuccess) { ctx->last_hip = (int)w; result = JPEG_AMD_EHIP; break; }
+        }
+        if (k + 1 < nchunks) {
+            { std::lock_guard<std::mutex> g(queue.m); queue.open_chunks = std::max(queue.open_chunks, k + 2); }
+            queue.cv.notify_all();
+        }
     }
     if (drainer.joinable()) drainer.join();
     if (result == JPEG_AMD_OK) result = drain_status;
     if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->file_d2h); return result; }
     JA_TRY(drain(nchunks - 1));
     return JPEG_AMD_OK;
+}
+
+}  // namespace
+
+int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[],
+                              int n_images, int nthreads, int cosited, jpeg_amd_color color,
+                              uint8_t *h_pixels, size_t pixel_stride, jpeg_amd_frame_info *info_out)
+try {
+    if (!h_pixels) return JPEG_AMD_EINVAL;
+    return decompress_batch_impl(ctx, h_jpeg, nbytes, n_images, nthreads, cosited, color, h_pixels, nullptr, pixel_stride, info_out);
+}
+JA_NOTHROW_TAIL
+
+int jpeg_amd_decompress_batch_device(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[],
+                                     int n_images, int nthreads, int cosited, jpeg_amd_color color,
+                                     uint8_t *d_pixels, size_t pixel_stride, jpeg_amd_frame_info *info_out)
+try {
+    if (!d_pixels) return JPEG_AMD_EINVAL;
+    return decompress_batch_impl(ctx, h_jpeg, nbytes, n_images, nthreads, cosited, color, nullptr, d_pixels, pixel_stride, info_out);
 }
 JA_NOTHROW_TAIL
 
@@ -1198,6 +1423,7 @@ try {
     // its download) and the pixels of chunk `stage` are copied into its pinned slot (stage < nchunks).  The caller's pixels
     // are pageable memory: copying them to pinned memory on all threads and uploading from there is what keeps the upload
     // asynchronous and at the speed of the link.
+    WorkerPool pool(std::min(nthreads, 2 * chunk));
     auto host_region = [&](int code, int stage) -> int {
         int m_code = 0, m_stage = 0;
         const char *planes_host = nullptr;
@@ -1213,7 +1439,7 @@ try {
         }
         std::vector<int> status((size_t)std::max(m_code, 1), JPEG_AMD_OK);
         const int copies = (int)(per_image * (size_t)m_stage);
-        run_parallel(nthreads, m_code + copies, [&](int j) {
+        pool.run(m_code + copies, [&](int j) {
             if (j < m_code) {
                 const int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
                 for (int c = 0; c < nc; ++c) planes[c] = reinterpret_cast<const int16_t *>(planes_host + coef_off[c]) + plane[c] * j;

@@ -47,6 +47,12 @@ hipError_t launch_idct_plane(hipStream_t stream, int n_images, const int16_t *d_
                              int precision, void *d_plane, size_t plane_stride,
                              bool out_u8);
 
+// Sparse coefficients (entropy.cpp, jpeg_amd_jpeg_decode_sparse) -> the planes.  d_skip: optional per-image flags, nonzero =
+// leave that image's planes alone.
+hipError_t launch_expand_sparse(hipStream_t stream, int n_images, const jpeg_amd_layout &layout, const uint32_t *d_desc,
+                                size_t desc_stride, const uint32_t *d_entries, size_t entries_stride, const uint8_t *d_skip,
+                                const PlaneSetMut &coef);
+
 // a9 (+ a11/a12): upsample + interleave, written as Rectangular uint16, or colour-converted
 // straight to YCbCr / RGB bytes.  Planes are uint16 (or uint8 when planes_u8).
 hipError_t launch_planar_to_pixels(hipStream_t stream, int n_images,

@@ -341,11 +341,80 @@ __global__ __launch_bounds__(kThreads) void k_fdct_plane(
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
 
+// ---- sparse coefficients -> planes (the device side of jpeg_amd_jpeg_decode_sparse, entropy.cpp) -------------------------
+// Eight work-items per block, one 16-byte octet of the block each: they walk the block's entries together (the same address
+// for all eight: one fetch) and keep what falls into their octet; a workgroup writes 32 whole blocks = 4 KiB in a row.
+// Blocks no scan reached (descriptor 0xFFFFFFFF) and images flagged in `skip` (their planes were uploaded as they are) aside,
+// every byte of the planes is written: no memset in front.
+struct ExpandArgs {
+    const uint32_t *desc;      size_t desc_stride;       // per image: one descriptor per block, planes in frame order
+    const uint32_t *entries;   size_t entries_stride;    // per image: the entry arena
+    const uint8_t *skip;                                 // optional, per image
+    int16_t *coef[JPEG_AMD_MAX_PLANES];
+    size_t coef_stride[JPEG_AMD_MAX_PLANES];
+    uint32_t first[JPEG_AMD_MAX_PLANES + 1];             // first[p]: blocks of the planes before p
+    int nplanes;
+};
+
+__global__ __launch_bounds__(kThreads) void k_expand_sparse(ExpandArgs a)
+{
+    const int img = blockIdx.y;
+    if (a.skip && a.skip[img]) return;
+    const uint32_t b = blockIdx.x * (kThreads / 8) + (threadIdx.x >> 3);
+    if (b >= a.first[a.nplanes]) return;
+    const uint32_t octet = threadIdx.x & 7;
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < JPEG_AMD_MAX_PLANES; ++q) p += (q < a.nplanes && b >= a.first[q]);
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t at = a.desc[img * a.desc_stride + b];
+    if (at != 0xffffffffu) {
+        const uint32_t *e = a.entries + img * a.entries_stride;
+        for (;; ++at) {
+            const uint32_t v = e[at];
+            const uint32_t pos = (v >> 16) & 63;
+            if ((pos >> 3) == octet) {
+                const uint32_t half = (pos & 1) * 16, word = (pos >> 1) & 3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (word == (uint32_t)k) w[k] = (w[k] & ~(0xffffu << half)) | ((v & 0xffffu) << half);
+            }
+            if (v >> 31) break;
+        }
+    }
+    int16_t *dst = a.coef[0];
+    size_t stride = a.coef_stride[0];
+    uint32_t first = a.first[0];
+#pragma unroll
+    for (int q = 1; q < JPEG_AMD_MAX_PLANES; ++q)
+        if (p == q) { dst = a.coef[q]; stride = a.coef_stride[q]; first = a.first[q]; }
+    *reinterpret_cast<uint4 *>(dst + img * stride + (size_t)(b - first) * 64 + 8 * octet) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 }  // namespace
 
 // =======================================================================================
 // launchers
 // =======================================================================================
+
+hipError_t launch_expand_sparse(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const uint32_t *d_desc, size_t desc_stride,
+                                const uint32_t *d_entries, size_t entries_stride, const uint8_t *d_skip, const PlaneSetMut &coef)
+{
+    ExpandArgs a{};
+    a.desc = d_desc; a.desc_stride = desc_stride; a.entries = d_entries; a.entries_stride = entries_stride; a.skip = d_skip;
+    a.nplanes = L.nplanes;
+    uint32_t blocks = 0;
+    for (int p = 0; p < L.nplanes; ++p) {
+        a.coef[p] = static_cast<int16_t *>(coef.ptr[p]); a.coef_stride[p] = coef.stride[p];
+        a.first[p] = blocks;
+        blocks += (uint32_t)L.units_x[p] * (uint32_t)L.units_y[p];
+    }
+    for (int p = L.nplanes; p <= JPEG_AMD_MAX_PLANES; ++p) a.first[p] = blocks;
+    if (blocks == 0 || n_images == 0) return hipSuccess;
+    const dim3 grid((blocks + kThreads / 8 - 1) / (kThreads / 8), n_images);
+    hipLaunchKernelGGL(k_expand_sparse, grid, dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_idct_plane(hipStream_t stream, int n_images, const int16_t *d_coef,
                              size_t coef_stride, QuantaRef q, int qi, int ux, int uy,

@@ -180,3 +180,88 @@ def test_decompress_batch_over_several_chunks_pageable_and_pinned_output(ctx, pi
         for i in range(n):
             assert G.sha(out[i * stride:i * stride + w * h * 3]) == G.entry(names[i % len(names)])["gold"]["rgb_sha256"], (i, threads)
             assert not out[i * stride + w * h * 3:(i + 1) * stride].any()
+
+
+def test_sparse_coefficients_expand_to_the_planes_on_the_device(ctx):
+    """jpeg_amd_jpeg_decode_sparse (host) + jpeg_amd_spectral_expand_batch (device) = the planes of
+    jpeg_amd_jpeg_decode_spectral, for a batch of sequential fixtures of one geometry; a skipped image keeps its planes."""
+    import torch
+    from _sparse import sparse_decode
+    lib = _lib.lib()
+    names = ["grayscale-sequential-1.jpg", "grayscale-sequential-2.jpg", "grayscale-sequential-1.jpg"]   # one geometry (640 x 359)
+    datas = [open(G.path(G.entry(n)["file"]), "rb").read() for n in names]
+    datas.append(open(G.path(G.entry("color-sequential-1.jpg")["file"]), "rb").read())   # ... and a three-plane one, alone
+    for group in (datas[:3], datas[3:]):
+        _expand_on_device(ctx, lib, group)
+
+
+def _expand_on_device(ctx, lib, datas):
+    import torch
+    from _sparse import sparse_decode
+    info = _lib.FrameInfo()
+    buf = (C.c_uint8 * len(datas[0])).from_buffer_copy(datas[0])
+    assert lib.jpeg_amd_jpeg_inspect(buf, len(datas[0]), C.byref(info)) == 0
+    nc = info.ncomponents
+    units = [(info.units_x[c], info.units_y[c]) for c in range(nc)]
+    blocks = sum(a * b for a, b in units)
+    n = len(datas)
+    cap = 64 * blocks
+    desc = np.zeros((n, blocks), np.uint32)
+    ent = np.zeros((n, cap), np.uint32)
+    want = []
+    for i, d in enumerate(datas):
+        st, de, en, _q = sparse_decode(lib, d, info)
+        assert st == 0
+        desc[i] = de
+        ent[i, :en.size] = en
+        planes = [np.zeros((b, a, 64), np.int16) for a, b in units]
+        b2 = (C.c_uint8 * len(d)).from_buffer_copy(d)
+        q2 = np.zeros((4, 64), np.uint16)
+        assert lib.jpeg_amd_jpeg_decode_spectral(b2, len(d), _lib.ptr_array([p.ctypes.data for p in planes]), q2.ctypes.data, None) == 0
+        want.append(planes)
+    dev = ctx.torch_device
+    d_desc, d_ent = torch.from_numpy(desc.view(np.int32)).to(dev), torch.from_numpy(ent.view(np.int32)).to(dev)
+    skip = torch.tensor([0] * (n - 1) + [1 if n > 1 else 0], dtype=torch.uint8, device=dev)
+    coefs = [torch.full((n, 64 * a * b), 77, dtype=torch.int16, device=dev) for a, b in units]
+    L = _lib.Layout()
+    L.width, L.height, L.precision, L.nplanes = info.width, info.height, 8, nc
+    L.scale_x, L.scale_y = info.scale_x, info.scale_y
+    for c in range(nc):
+        L.factor_x[c], L.factor_y[c], L.units_x[c], L.units_y[c], L.qi[c] = info.factor_x[c], info.factor_y[c], units[c][0], units[c][1], 0
+    st = lib.jpeg_amd_spectral_expand_batch(ctx.handle, C.byref(L), n, d_desc.data_ptr(), blocks, d_ent.data_ptr(), cap, skip.data_ptr(),
+                                            _lib.ptr_array([c.data_ptr() for c in coefs]), _lib.size_array([64 * a * b for a, b in units]))
+    assert st == 0, st
+    torch.cuda.synchronize()
+    for i in range(n):
+        for c in range(nc):
+            got = coefs[c][i].cpu().numpy().reshape(want[i][c].shape)
+            if i == n - 1 and n > 1:
+                assert (got == 77).all()
+            else:
+                assert (got == want[i][c]).all(), (i, c)
+
+
+def test_decompress_batch_device_leaves_the_pixels_on_the_device(ctx):
+    """jpeg_amd_decompress_batch_device: 70 files (three chunks; sequential ones travel as sparse coefficients, the
+    progressive one as planes -- both kinds in every chunk), the pixels stay in device memory, with a pitch."""
+    import torch
+    import jpeg_amd as J
+    lib = _lib.lib()
+    names = ["color-sequential-1.jpg", "color-progressive-1.jpg", "color-sequential-restart.jpg"]
+    names = [n for n in names if (G.entry(n)["width"], G.entry(n)["height"]) == (G.entry(names[0])["width"], G.entry(names[0])["height"])]
+    files = [np.fromfile(G.path(G.entry(n)["file"]), np.uint8) for n in names]
+    n = 70
+    batch = [files[i % len(files)] for i in range(n)]
+    w, h = G.entry(names[0])["width"], G.entry(names[0])["height"]
+    stride = w * h * 3 + 48
+    out = torch.zeros(n * stride, dtype=torch.uint8, device=ctx.torch_device)
+    ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in batch])
+    sizes = (C.c_size_t * n)(*[f.size for f in batch])
+    for threads in (1, 4):
+        out.zero_()
+        st = lib.jpeg_amd_decompress_batch_device(ctx.handle, ptrs, sizes, n, threads, 0, J.RGB.code, out.data_ptr(), stride, None)
+        assert st == 0, st
+        got = out.cpu().numpy()
+        for i in range(n):
+            assert G.sha(got[i * stride:i * stride + w * h * 3]) == G.entry(names[i % len(names)])["gold"]["rgb_sha256"], (i, threads)
+            assert not got[i * stride + w * h * 3:(i + 1) * stride].any()

@@ -36,6 +36,16 @@ for t in args.threads:
         dt = time.perf_counter() - t0
         assert st == 0, st
     print(f"  {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s  {mb/dt:8.0f} MB/s of JPEG")
+# the same with the pixels left on the device (sparse coefficients up, nothing down)
+d_out = torch.zeros((n, W * H * 3), dtype=torch.uint8, device=ctx.torch_device)
+for t in args.threads:
+    for rep in range(2):
+        t0 = time.perf_counter()
+        st = lib.jpeg_amd_decompress_batch_device(ctx.handle, ptrs, sizes, n, t, 0, J.RGB.code, d_out.data_ptr(), 0, None)
+        dt = time.perf_counter() - t0
+        assert st == 0, st
+    print(f"  to device memory {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s  {mb/dt:8.0f} MB/s of JPEG")
+assert (d_out.cpu().numpy() == out).all()
 # host entropy decode alone, one thread
 info = _lib.FrameInfo(); f = batch[0]
 planes = [np.zeros((a[1], a[0], 64), np.int16) for a in layout.units((W, H))]; q = np.zeros((4, 64), np.uint16)

@@ -806,6 +806,21 @@ def extras(J, ctx, d_quanta, q_np, sync, args, workload="c3"):
             "files": n, "host_threads": threads, "ms": round(best * 1e3, 2), "images_per_s": round(n / best, 1),
             "Mpixels_per_s": round(n * W * H / best / 1e6, 1), "jpeg_MB_per_s": round(sum(f.size for f in batch) / best / 1e6, 1),
             "note": "host Huffman decode + H2D + fused decode + D2H; bounded by PCIe and the host, not by the kernels"}
+        # the same files with the pixels LEFT ON THE DEVICE (sparse coefficients up, nothing down)
+        d_pixels = torch.empty((n, W * H * 3), dtype=torch.uint8, device=ctx.torch_device)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            st = lib.jpeg_amd_decompress_batch_device(ctx.handle, ptrs, sizes, n, threads, 0, _lib.COLOR_RGB8, d_pixels.data_ptr(), 0, None)
+            dt = time.perf_counter() - t0
+            assert st == 0, st
+            best = dt if best is None else min(best, dt)
+        out["file_path_1080p_to_device"] = {
+            "files": n, "host_threads": threads, "ms": round(best * 1e3, 2), "images_per_s": round(n / best, 1),
+            "Mpixels_per_s": round(n * W * H / best / 1e6, 1), "jpeg_MB_per_s": round(sum(f.size for f in batch) / best / 1e6, 1),
+            "same_pixels_as_the_host_path": bool((d_pixels.cpu().numpy() == pixels).all()),
+            "note": "host Huffman decode into sparse coefficients + H2D + expansion + fused decode; bounded by the host"}
+        del d_pixels
         # ... and the other way: the pixels just decoded (host memory) -> baseline JPEG bytes in host memory
         # (jpeg_amd_compress_batch: pinned staging + fused encode + host Huffman coder with optimised tables)
         from jpeg_amd.api import _scan_array, _metadata_array

@@ -166,7 +166,7 @@ __device__ __forceinline__ void fdct_quantise(const float (&g)[64], const float 
 // is formed in 64 bits by the storing lane), or ~0u for a block outside the plane; the producer's
 // index reaches the storing lane through ds_bpermute.  LDS operations of one wave execute in order, so
 // no barrier is needed; all 64 lanes must call this together.
-__device__ __forceinline__ void wave_store_blocks(const uint32_t (&w)[32], uint32_t *stage, int lane,
+__device__ __forceinline__ __attribute__((unused)) void wave_store_blocks(const uint32_t (&w)[32], uint32_t *stage, int lane,
                                                   int16_t *plane, uint32_t block)
 {
     uint4 *mine = reinterpret_cast<uint4 *>(stage) + 8 * lane;
@@ -237,7 +237,7 @@ template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN, int TY = ETY, bool
 #ifndef JA_X_ENC_PERHALF_WAVES
 #define JA_X_ENC_PERHALF_WAVES 2
 #endif
-__global__ __launch_bounds__(kThreads, (TY == 8 ? 4 : (CHROMA && SX == 1 && SY == 1) ? 2 : (CHROMA && SX * SY == 2) ? JA_X_ENC_PERHALF_WAVES : 3)) void k_encode_fused(EncArgs a)
+__global__ __launch_bounds__(kThreads, (TY == 8 ? ((CHROMA && SX == 1 && SY == 1) ? 3 : 4) : (CHROMA && SX == 1 && SY == 1) ? 2 : (CHROMA && SX * SY == 2) ? JA_X_ENC_PERHALF_WAVES : 3)) void k_encode_fused(EncArgs a)
 {
     // (waves per SIMD declared above: 4 for the 8-row tiles, 2 for 4:4:4 -- its 65 KiB of LDS and 256 VGPRs admit no
     // more -- 2 for 4:2:2 / 4:4:0, and 3 for the 16-row tiles of the JA_X_ENC_TY experiment)

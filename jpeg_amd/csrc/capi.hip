@@ -1139,21 +1139,33 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
         skip[i] = 1;
         used_of[slot][(size_t)i] = 0;
         if (!h_jpeg[file]) return JPEG_AMD_EINVAL;
-        // geometry first: the planes are sized for image 0
-        int st = jpeg_amd_jpeg_inspect(h_jpeg[file], nbytes[file], &f);
-        if (st == JPEG_AMD_OK) {
+        auto same_geometry = [&]() {                         // one geometry per batch: the buffers are sized for image 0
             bool same = f.width == fi.width && f.height == fi.height && f.precision == 8 && f.ncomponents == nc;
             for (int c = 0; same && c < nc; ++c)
                 same = f.factor_x[c] == fi.factor_x[c] && f.factor_y[c] == fi.factor_y[c];
-            if (!same) st = JPEG_AMD_EINVAL;                 // one geometry per batch
-        }
+            return same;
+        };
+        int st = JPEG_AMD_OK;
+        // Sparse first, without a look at the headers beforehand: the decoder itself refuses a frame with more blocks than the
+        // descriptor array holds and never writes past the arena, so a file of another geometry is caught afterwards.
         // (spare threads only help a file that has restart intervals; such a file is decoded into planes on `inner` threads)
-        if (st == JPEG_AMD_OK && (inner == 1 || f.restart_interval == 0) && f.process != 2) {
+        bool sparse_done = false;
+        if (inner == 1 || fi.restart_interval == 0) {
             uint32_t *sp = reinterpret_cast<uint32_t *>(host + sparse_off) + sparse_elems * (size_t)i;
             size_t n = 0;
-            const int ss = jpeg_amd_jpeg_decode_sparse(h_jpeg[file], nbytes[file], sp, blocks, sp + blocks, arena, &n, quanta, nullptr);
-            if (ss == JPEG_AMD_OK) { skip[i] = 0; used_of[slot][(size_t)i] = n; }
-            else if (ss != JPEG_AMD_ENOSUP) st = ss;
+            const int ss = jpeg_amd_jpeg_decode_sparse(h_jpeg[file], nbytes[file], sp, blocks, sp + blocks, arena, &n, quanta, &f);
+            if (ss == JPEG_AMD_OK) {
+                if (!same_geometry()) return JPEG_AMD_EINVAL;
+                skip[i] = 0; used_of[slot][(size_t)i] = n;
+                sparse_done = true;
+            } else if (ss != JPEG_AMD_ENOSUP) {
+                // (EINVAL may be "more blocks than image 0": the same verdict either way)
+                return ss;
+            }
+        }
+        if (!sparse_done) {
+            st = jpeg_amd_jpeg_inspect(h_jpeg[file], nbytes[file], &f);
+            if (st == JPEG_AMD_OK && !same_geometry()) st = JPEG_AMD_EINVAL;
         }
         if (st == JPEG_AMD_OK && skip[i])
             st = jpeg_amd_jpeg_decode_spectral_mt(h_jpeg[file], nbytes[file], planes, quanta, nullptr, inner > 1 && auto_threads ? 0 : inner);

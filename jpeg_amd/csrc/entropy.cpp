@@ -341,7 +341,7 @@ struct Component {
 struct SparseOut {
     uint32_t *desc = nullptr;
     uint32_t *entries = nullptr;
-    size_t capacity = 0, n = 0;
+    size_t ndesc = 0, capacity = 0, n = 0;
 };
 constexpr uint32_t kSparseAbsent = 0xffffffffu, kSparseLast = 0x80000000u;
 int16_t g_sparse_sentinel[1];   // what Component::coef points at in a sparse decode (never dereferenced)
@@ -982,6 +982,10 @@ struct Decoder {
                         have_frame = true;
                         if (sparse) {
                             if (info.process == 2) return JPEG_AMD_ENOSUP;      // progressive scans add to a block: planes only
+                            size_t frame_blocks = 0;
+                            for (const Component &c : comps) frame_blocks += (size_t)c.ux * c.uy;
+                            if (frame_blocks > sparse->ndesc || frame_blocks >= kSparseAbsent) return JPEG_AMD_EINVAL;   // the caller's array is too small
+                            std::memset(sparse->desc, 0xff, frame_blocks * sizeof(uint32_t));
                             for (int c = 0; c < info.ncomponents; ++c) comps[c].coef = g_sparse_sentinel;
                         } else if (coef)
                             for (int c = 0; c < info.ncomponents; ++c) {
@@ -1120,17 +1124,8 @@ int jpeg_amd_jpeg_decode_sparse(const uint8_t *data, size_t nbytes, uint32_t *h_
 {
     if (!data || !h_desc || !h_entries || !nentries || !h_quanta) return JPEG_AMD_EINVAL;
     JA_NOTHROW_BEGIN
-    {   // the descriptor array must hold every block of the frame
-        Decoder probe{data, nbytes};
-        const int st = probe.run(nullptr, nullptr);
-        if (st != JPEG_AMD_OK) return st;
-        size_t blocks = 0;
-        for (const Component &c : probe.comps) blocks += (size_t)c.ux * c.uy;
-        if (blocks > ndesc || blocks >= kSparseAbsent) return JPEG_AMD_EINVAL;
-        std::memset(h_desc, 0xff, blocks * sizeof(uint32_t));
-    }
     SparseOut out;
-    out.desc = h_desc; out.entries = h_entries; out.capacity = capacity;
+    out.desc = h_desc; out.ndesc = ndesc; out.entries = h_entries; out.capacity = capacity;
     Decoder d{data, nbytes};
     d.nthreads = 1;
     d.sparse = &out;

@@ -154,6 +154,19 @@ int jpeg_amd_spectral_rectangular(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layo
                                   const int16_t *const d_coef[], const uint16_t *h_quanta, int ntables,
                                   int cosited, uint16_t *d_rect);
 
+/* Fused Rectangular -> Spectral: == decomposed().fdct(quanta:) bit for bit (encode.swift:389-425, 199-248) -- what
+ * Rectangular.compress(stream:quanta:) runs in front of the entropy coder (encode.swift:2031) -- for ANY JPEG.Format, the
+ * mirror image of jpeg_amd_spectral_rectangular: the layouts that take one launch there take one here (no Planar
+ * intermediate in HBM, the reference's literal operation sequence), every other layout runs the staged kernels through the
+ * context's scratch.  d_rect: uint16 [H][W][nplanes]; d_coef[p]: int16 [units_y][units_x][64], zigzag. */
+int jpeg_amd_rectangular_spectral_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout, int n_images,
+                                        const uint16_t *d_rect, size_t rect_stride, const uint16_t *d_quanta,
+                                        size_t quanta_stride, int ntables, int16_t *const d_coef[],
+                                        const size_t coef_stride[]);
+/* single image, host tables */
+int jpeg_amd_rectangular_spectral(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout, const uint16_t *d_rect,
+                                  const uint16_t *h_quanta, int ntables, int16_t *const d_coef[]);
+
 /* ---- encode stages (device-resident) ---------------------------------------------- */
 
 /* Rectangular.pack(size:layout:metadata:pixels:)  encode.swift:453-464 */
@@ -203,6 +216,9 @@ int jpeg_amd_host_decode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
 int jpeg_amd_host_spectral_rectangular(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,
                                        const int16_t *const h_coef[], const uint16_t *h_quanta, int ntables,
                                        int cosited, uint16_t *h_rect);
+/* decomposed().fdct(quanta:) with host buffers, likewise (jpeg_amd_rectangular_spectral) */
+int jpeg_amd_host_rectangular_spectral(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout, const uint16_t *h_rect,
+                                       const uint16_t *h_quanta, int ntables, int16_t *const h_coef[]);
 int jpeg_amd_host_rectangular_pack(jpeg_amd_ctx *ctx, const uint8_t *h_pixels, size_t npixels,
                                    int nplanes, jpeg_amd_color color, uint16_t *h_rect);
 int jpeg_amd_host_rectangular_decomposed(jpeg_amd_ctx *ctx, const jpeg_amd_layout *layout,

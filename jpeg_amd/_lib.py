@@ -64,6 +64,9 @@ SIGNATURES = {
     "jpeg_amd_spectral_rectangular_batch": (C.c_int, [_p, _L, C.c_int, _pp, _szp, _p, C.c_size_t, C.c_int, C.c_int, _p, C.c_size_t]),
     "jpeg_amd_spectral_rectangular": (C.c_int, [_p, _L, _pp, _p, C.c_int, C.c_int, _p]),
     "jpeg_amd_host_spectral_rectangular": (C.c_int, [_p, _L, _pp, _p, C.c_int, C.c_int, _p]),
+    "jpeg_amd_rectangular_spectral_batch": (C.c_int, [_p, _L, C.c_int, _p, C.c_size_t, _p, C.c_size_t, C.c_int, _pp, _szp]),
+    "jpeg_amd_rectangular_spectral": (C.c_int, [_p, _L, _p, _p, C.c_int, _pp]),
+    "jpeg_amd_host_rectangular_spectral": (C.c_int, [_p, _L, _p, _p, C.c_int, _pp]),
     "jpeg_amd_rectangular_pack": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_int, _p]),
     "jpeg_amd_rectangular_decomposed": (C.c_int, [_p, _L, _p, _pp]),
     "jpeg_amd_fdct_plane": (C.c_int, [_p, _p, C.c_int, C.c_int, _p, C.c_int, _p]),

@@ -523,6 +523,28 @@ class Rectangular:
             "jpeg_amd_rectangular_decomposed", self.ctx.handle)
         return Planar(self.ctx, self.size, self.layout, out)
 
+    def spectral(self, quanta: Dict[int, Sequence[int]]) -> Spectral:
+        """decomposed().fdct(quanta:) in one call (encode.swift:389-425, 353-370): one launch for formats whose planes lie at the
+        image's scale or at half of it (jpeg_amd_rectangular_spectral), the staged kernels otherwise -- same coefficients."""
+        torch = _torch()
+        keys: List[int] = []
+        q = []
+        for c in self.layout.planes:
+            if c.qi not in quanta:
+                raise _lib.JpegAmdError(_lib.EINVAL, f"missing quantization table for quanta key {c.qi}")
+            if c.qi not in keys:
+                keys.append(c.qi)
+            q.append(keys.index(c.qi))
+        tables = [np.asarray(quanta[k], np.uint16).reshape(64) for k in keys]
+        units = self.layout.units(self.size)
+        L = self.layout.c_layout(self.size, units, q)
+        out = [self.ctx.empty(64 * ux * uy, torch.int16).view(uy, ux, 64) for ux, uy in units]
+        qarr, qptr = _quanta_array(tables)
+        _lib.check(_lib.lib().jpeg_amd_rectangular_spectral(
+            self.ctx.handle, C.byref(L), self.values.data_ptr(), qptr, len(tables), _ptrs(out)),
+            "jpeg_amd_rectangular_spectral", self.ctx.handle)
+        return Spectral(self.ctx, self.size, self.layout, out, tables, q)
+
     @classmethod
     def encode(cls, ctx, size, layout, pixels, quanta: Dict[int, Sequence[int]], color=RGB) -> Spectral:
         """Fused pack(...).decomposed().fdct(quanta:) -> Spectral."""
@@ -551,8 +573,8 @@ class Rectangular:
                  path=None, restart_interval: int = 0) -> bytes:
         """Rectangular.compress(stream:quanta:) / compress(path:quanta:) -- encode.swift:2031,
         os.swift:412: decomposed().fdct(quanta:).compress(...)."""
-        return self.decomposed().fdct(quanta).compress(scans, process=process, metadata=metadata, path=path,
-                                                         restart_interval=restart_interval)
+        return self.spectral(quanta).compress(scans, process=process, metadata=metadata, path=path,
+                                              restart_interval=restart_interval)
 
     def host_values(self) -> np.ndarray:
         return self.values.cpu().numpy().view(np.uint16)

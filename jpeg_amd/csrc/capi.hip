@@ -769,6 +769,57 @@ int jpeg_amd_encode_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_ima
     return JPEG_AMD_OK;
 }
 
+int jpeg_amd_rectangular_spectral_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, int n_images, const uint16_t *d_rect,
+                                        size_t rect_stride, const uint16_t *d_quanta, size_t quanta_stride, int ntables,
+                                        int16_t *const d_coef[], const size_t coef_stride[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (n_images < 0 || n_images > 65535) return JPEG_AMD_EINVAL;
+    if (n_images == 0) return JPEG_AMD_OK;
+    if (!d_rect || !d_quanta || !d_coef || !coef_stride) return JPEG_AMD_EINVAL;
+    PlaneSetMut cs{};
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (plane_samples(L, p) && !d_coef[p]) return JPEG_AMD_EINVAL;
+        cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p];
+    }
+    if (generic_encode_supported(*L)) {
+        JA_HIP(ctx, launch_generic_encode(ctx->stream, n_images, *L, d_rect, rect_stride, QuantaRef{d_quanta, quanta_stride}, cs));
+        return JPEG_AMD_OK;
+    }
+    // staged path (any factors): decomposed() into uint16 scratch planes, then fdct(quanta:) plane by plane
+    size_t offset[JPEG_AMD_MAX_PLANES], total = 0;
+    for (int p = 0; p < L->nplanes; ++p) {
+        offset[p] = total;
+        total += align256(plane_samples(L, p) * (size_t)n_images * sizeof(uint16_t));
+    }
+    JA_TRY(ensure_scratch(ctx, total));
+    PlaneSetMut ps{};
+    for (int p = 0; p < L->nplanes; ++p) {
+        ps.ptr[p] = static_cast<uint8_t *>(ctx->scratch) + offset[p];
+        ps.stride[p] = plane_samples(L, p);
+    }
+    JA_HIP(ctx, launch_decompose(ctx->stream, n_images, *L, d_rect, rect_stride * sizeof(uint16_t), PixelKind::Rect16, ps));
+    for (int p = 0; p < L->nplanes; ++p) {
+        if (plane_samples(L, p) == 0) continue;
+        JA_HIP(ctx, launch_fdct_plane(ctx->stream, n_images, static_cast<const uint16_t *>(ps.ptr[p]), ps.stride[p],
+                                      QuantaRef{d_quanta, quanta_stride}, L->qi[p], L->units_x[p], L->units_y[p], L->precision,
+                                      d_coef[p], coef_stride[p]));
+    }
+    return JPEG_AMD_OK;
+}
+
+int jpeg_amd_rectangular_spectral(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const uint16_t *d_rect,
+                                  const uint16_t *h_quanta, int ntables, int16_t *const d_coef[])
+{
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    const uint16_t *d_q = nullptr;
+    JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
+    const size_t zero[JPEG_AMD_MAX_PLANES] = {0, 0, 0, 0};
+    return jpeg_amd_rectangular_spectral_batch(ctx, L, 1, d_rect, 0, d_q, 0, ntables, d_coef, zero);
+}
+
 int jpeg_amd_encode(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const uint8_t *d_pixels,
                     jpeg_amd_color color, const uint16_t *h_quanta, int ntables,
                     int16_t *const d_coef[])
@@ -921,6 +972,24 @@ try {
     JA_TRY(bag.alloc(rect_samples(L) * 2, (void **)&d_rect));
     JA_TRY(jpeg_amd_spectral_rectangular(ctx, L, d_coef, h_quanta, ntables, cosited, d_rect));
     JA_TRY(bag.download(h_rect, d_rect, rect_samples(L) * 2));
+    JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_AMD_OK;
+}
+JA_NOTHROW_TAIL
+
+int jpeg_amd_host_rectangular_spectral(jpeg_amd_ctx *ctx, const jpeg_amd_layout *L, const uint16_t *h_rect,
+                                       const uint16_t *h_quanta, int ntables, int16_t *const h_coef[])
+try {
+    JA_TRY(bind(ctx));
+    JA_TRY(check_layout(L, ntables));
+    if (!h_rect || !h_coef) return JPEG_AMD_EINVAL;
+    DeviceBag bag(ctx);
+    uint16_t *d_rect = nullptr;
+    JA_TRY(bag.upload(h_rect, rect_samples(L) * 2, (void **)&d_rect));
+    int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int p = 0; p < L->nplanes; ++p) JA_TRY(bag.alloc(plane_samples(L, p) * 2, (void **)&d_coef[p]));
+    JA_TRY(jpeg_amd_rectangular_spectral(ctx, L, d_rect, h_quanta, ntables, d_coef));
+    for (int p = 0; p < L->nplanes; ++p) JA_TRY(bag.download(h_coef[p], d_coef[p], plane_samples(L, p) * 2));
     JA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JPEG_AMD_OK;
 }

@@ -373,10 +373,15 @@ __device__ __forceinline__ uint32_t clamp_trunc(float v, float limit)
     return (uint32_t)__builtin_amdgcn_fmed3f(v, 0.0f, limit);
 }
 
-// Float.rounded() / rounding: .toNearestOrAwayFromZero
+// Float.rounded() / rounding: .toNearestOrAwayFromZero -- exactly, for either sign, and without a select: with r = trunc(v) the
+// difference d = v - r is exact and lies in (-1, 1), 2 d is exact, and trunc(2 d) is +-1 exactly when |d| >= 1/2 (0 otherwise);
+// |v| >= 2^23 is its own truncation.  (roundf() compiles to a sequence around v_cndmask_b32, which issues ten times slower
+// than anything else on gfx950: profiles/r05_probe_valu_classes.txt.)
 __device__ __forceinline__ float round_half_away(float v)
 {
-    return roundf(v);
+    const float r = __builtin_truncf(v);
+    const float d = v - r;
+    return r + __builtin_truncf(d + d);
 }
 
 }  // namespace jpeg_amd

@@ -60,6 +60,11 @@ hipError_t launch_planar_to_pixels(hipStream_t stream, int n_images,
                                    bool planes_u8, bool cosited, PixelKind kind,
                                    void *d_out, size_t out_stride_bytes);
 
+// ... and back: Rectangular -> Spectral in one launch (decomposed() + fdct(quanta:), encode.swift:389-425, 199-248), same layouts.
+bool       generic_encode_supported(const jpeg_amd_layout &layout);
+hipError_t launch_generic_encode(hipStream_t stream, int n_images, const jpeg_amd_layout &layout, const uint16_t *d_rect,
+                                 size_t rect_stride, QuantaRef q, const PlaneSetMut &coef);
+
 // a10..a12: Rectangular.unpack(as:) for YCbCr / RGB.
 hipError_t launch_unpack(hipStream_t stream, const uint16_t *d_rect, size_t npixels,
                          int nplanes, jpeg_amd_color color, uint8_t *d_pixels);

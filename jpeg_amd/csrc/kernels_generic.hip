@@ -286,6 +286,181 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The other direction: Rectangular -> Spectral in ONE launch, replacing decomposed() -> fdct(quanta:) (encode.swift:389-425,
+// 199-248) for every layout the 8-bit fused encoder does not take.  The same literal operation sequence as kernels_stage.hip's
+// k_decompose + k_fdct_plane: a plane sample is the truncated Float quotient of the sum of the rectangular samples under it
+// (indices clamped to the image, encode.swift:403-422); the block is min(limit, .), level-shifted and transformed by dct.hpp's
+// fdct_block, every coefficient divided -- a true division -- by its modulated quantum and rounded half away from zero.
+//
+// One workgroup = a tile of 128 x 32 or 128 x 64 pixels (at the image's scale).  Phase A: the tile's plane samples into LDS, one per
+// work-item and step (every rectangular sample is fetched exactly once per plane it belongs to).  Phase B: one 8 x 8 block per
+// work-item from the LDS tile -- at most 64 per plane, 256 for four planes at full scale.  Phase C: the blocks' 128 bytes go
+// back through the same LDS (chunk-swizzled) and leave as whole runs of neighbouring blocks: every store instruction writes
+// 64 consecutive 16-byte chunks instead of 64 chunks 128 bytes apart.
+constexpr int GEW = 128;   // tile width in pixels; its height GEH is 32, or 64 where the blocks under 64 rows still fit 256 work-items
+
+struct GenEncPlane {
+    int16_t *coef;
+    size_t stride;        // elements between images
+    int ux, uy, rx, ry, qi;
+};
+struct GenEncArgs {
+    GenEncPlane pl[JPEG_AMD_MAX_PLANES];
+    const uint16_t *rect;
+    size_t rect_stride;   // elements between images
+    const uint16_t *quanta;
+    size_t quanta_stride;
+    int count, W, H;
+    float level, limit;   // encode.swift:215-218, :85
+    int tiles_x;
+};
+
+template <int COUNT, int GEH>
+__global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_encode(GenEncArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t raw[GEW * GEH * COUNT];    // the tile of Rectangular; later the blocks on their way out
+    extern __shared__ __attribute__((aligned(16))) uint16_t tile[];                // plane tiles: as many samples as the layout's planes have under a tile
+    __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                                // modulated tables (natural order, scale 8)
+
+    const int t = threadIdx.x, img = blockIdx.y;
+    const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
+    const int x0 = txi * GEW, y0 = tyi * GEH;
+    {
+        const int p = t >> 6, e = t & 63;
+        if (p < COUNT) sq[p][e] = modulate_entry(e & 7, e >> 3, 8.0f, a.quanta[img * a.quanta_stride + 64 * a.pl[p].qi + zigzag_of(e & 7, e >> 3)]);
+    }
+    // per plane (wave-uniform): the tile's sample rectangle and where it starts in LDS
+    int tw[COUNT], th[COUNT], first[COUNT + 1], fb[COUNT + 1];
+    first[0] = 0; fb[0] = 0;
+#pragma unroll
+    for (int p = 0; p < COUNT; ++p) {
+        tw[p] = GEW / a.pl[p].rx; th[p] = GEH / a.pl[p].ry;
+        first[p + 1] = first[p] + tw[p] * th[p];
+        fb[p + 1] = fb[p] + (tw[p] / 8) * (th[p] / 8);
+    }
+    // ---- phase A1: the tile of Rectangular as it lies in memory -> LDS, 16 bytes per work-item and step; a sample beyond the
+    //      image is the nearest one inside (encode.swift:415-417: the box clamps its indices), fetched one at a time ----
+    const uint16_t *rect = a.rect + img * a.rect_stride;
+    constexpr int RP = GEW * COUNT;                         // uint16 per tile row
+    for (int i = t; i < GEH * (RP / 8); i += kGThreads) {
+        const int row = i / (RP / 8), ch = i - row * (RP / 8);
+        const int yy = min(y0 + row, a.H - 1);
+        const uint16_t *src = rect + ((size_t)a.W * yy + x0) * COUNT;
+        uint4 v;
+        if (x0 + (8 * ch + 7) / COUNT <= a.W - 1) {
+            v = *reinterpret_cast<const uint4 *>(src + 8 * ch);          // (rows need not be 16-byte aligned)
+        } else {
+            uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int el = 8 * ch + e, px = el / COUNT, comp = el - px * COUNT;
+                const int xx = min(x0 + px, a.W - 1);
+                d[e >> 1] |= (uint32_t)rect[((size_t)a.W * yy + xx) * COUNT + comp] << (16 * (e & 1));
+            }
+            v = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        *reinterpret_cast<uint4 *>(raw + row * RP + 8 * ch) = v;
+    }
+    __syncthreads();
+    // ---- phase A2: Rectangular.decomposed() from there into the plane tiles.  The sum of the 1, 2 or 4 samples under a plane
+    //      sample is below 2^24, so Float(sum) is exact, its quotient by 1, 2 or 4 is exact, and the truncation of that
+    //      quotient (encode.swift:404, :422) is the sum shifted right ----
+    for (int i = t; i < first[COUNT]; i += kGThreads) {
+        int p = 0;
+#pragma unroll
+        for (int q = 1; q < COUNT; ++q) p += i >= first[q];
+        int f0 = first[0], w = tw[0], rx = a.pl[0].rx, ry = a.pl[0].ry;
+#pragma unroll
+        for (int q = 1; q < COUNT; ++q)
+            if (p == q) { f0 = first[q]; w = tw[q]; rx = a.pl[q].rx; ry = a.pl[q].ry; }
+        const int local = i - f0, ly = local / w, lx = local - ly * w;
+        const uint16_t *box = raw + (ly * ry) * RP + (lx * rx) * COUNT + p;
+        uint32_t sum = box[0];
+        if (rx == 2) sum += box[COUNT];
+        if (ry == 2) { sum += box[RP]; if (rx == 2) sum += box[RP + COUNT]; }
+        tile[i] = (uint16_t)(sum >> ((rx == 2) + (ry == 2)));
+    }
+    __syncthreads();
+
+    // ---- phase B: one block per work-item; block 4 l + w goes to lane l of wave w, so that a tile with fewer than 256 blocks
+    //      (96 for 4:2:0) keeps all four SIMDs busy with a partly filled wave each instead of two with full ones ----
+    bool have = false;
+    int p = 0, gbx = 0, gby = 0;
+    const int blk = fb[COUNT] > 160 ? t : 4 * (t & 63) + (t >> 6);   // (three or four full waves: as they come)
+    if (blk < fb[COUNT]) {
+#pragma unroll
+        for (int q = 1; q < COUNT; ++q) p += blk >= fb[q];
+        int b0 = fb[0], f0 = first[0], wpx = tw[0];
+#pragma unroll
+        for (int q = 1; q < COUNT; ++q)
+            if (p == q) { b0 = fb[q]; f0 = first[q]; wpx = tw[q]; }
+        const int nbx = wpx / 8, local = blk - b0, lby = local / nbx, lbx = local - lby * nbx;
+        int ux = a.pl[0].ux, uy = a.pl[0].uy, rx = a.pl[0].rx, ry = a.pl[0].ry;
+#pragma unroll
+        for (int q = 1; q < COUNT; ++q)
+            if (p == q) { ux = a.pl[q].ux; uy = a.pl[q].uy; rx = a.pl[q].rx; ry = a.pl[q].ry; }
+        gbx = x0 / (8 * rx) + lbx; gby = y0 / (8 * ry) + lby;
+        have = gbx < ux && gby < uy;
+        if (have) {
+            const uint16_t *src = tile + f0 + (8 * lby) * wpx + 8 * lbx;
+            // fdct_block (dct.hpp) with the load in front of its first pass and the quantiser inside its second: a row of samples
+            // is fetched when it is transformed, a column of coefficients divided, rounded and packed as soon as it exists
+            // (samples and coefficients all at once would hold the kernel at ~200 VGPRs)
+            float f[64];  // f[8*k + y]
+#pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + y * wpx);
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                float r[8], res[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) r[x] = fminf(a.limit, (float)((d[x >> 1] >> (16 * (x & 1))) & 0xffffu));   // encode.swift:85
+                fdct8<true>(r, a.level, res);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f[8 * k + y] = res[k];
+                __builtin_amdgcn_sched_barrier(0);   // a row at a time (all eight rows' loads up front cost 32 more registers)
+            }
+            // the coefficients go straight to the staging area (the raw tile is no longer needed: every work-item is past the
+            // barrier behind phase A2): int16 at its zigzag position z of block b, 16-byte chunk z / 8 at slot (z / 8) ^ (b & 7)
+            uint16_t *mine = raw + 64 * blk;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float r[8], res[8];
+#pragma unroll
+                for (int y = 0; y < 8; ++y) r[y] = f[8 * k + y];
+                fdct8<false>(r, 0.0f, res);
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int32_t c = (int32_t)round_half_away(res[h] / sq[p][8 * h + k]);   // encode.swift:225-240
+                    const int z = zigzag_of(k, h);
+                    mine[8 * ((z >> 3) ^ (blk & 7)) + (z & 7)] = (uint16_t)c;
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one column at a time: eight divisions in flight are register pressure enough
+            }
+        }
+    }
+    // ---- phase C: blocks out through LDS (the raw tile is no longer needed); chunk c of block t sits at slot c ^ (t & 7) ----
+    const uint4 *stage = reinterpret_cast<const uint4 *>(raw);
+    __syncthreads();
+    for (int j = t; j < 8 * fb[COUNT]; j += kGThreads) {
+        const int b = j >> 3, c = j & 7;
+        int q = 0;
+#pragma unroll
+        for (int r = 1; r < COUNT; ++r) q += b >= fb[r];
+        int b0 = fb[0], wpx = tw[0];
+        int16_t *coef = a.pl[0].coef;
+        size_t stride = a.pl[0].stride;
+        int ux = a.pl[0].ux, uy = a.pl[0].uy, rx = a.pl[0].rx, ry = a.pl[0].ry;
+#pragma unroll
+        for (int r = 1; r < COUNT; ++r)
+            if (q == r) { b0 = fb[r]; wpx = tw[r]; coef = a.pl[r].coef; stride = a.pl[r].stride; ux = a.pl[r].ux; uy = a.pl[r].uy; rx = a.pl[r].rx; ry = a.pl[r].ry; }
+        const int nbx = wpx / 8, local = b - b0, lby = local / nbx, lbx = local - lby * nbx;
+        const int bx = x0 / (8 * rx) + lbx, by = y0 / (8 * ry) + lby;
+        if (bx < ux && by < uy)
+            *reinterpret_cast<uint4 *>(coef + img * stride + (size_t)64 * ((size_t)by * ux + bx) + 8 * c) = stage[8 * b + (c ^ (b & 7))];
+    }
+}
+
 int tile_blocks(const jpeg_amd_layout &L, int th)
 {
     int n = 0;
@@ -348,6 +523,56 @@ hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd
     if (th == 64) { JA_GC(64) } else { JA_GC(32) }
 #undef JA_GC
 #undef JA_G
+    return hipGetLastError();
+}
+
+bool generic_encode_supported(const jpeg_amd_layout &L)
+{
+    return generic_fused_supported(L) && (long long)L.width * L.height * L.nplanes < (1LL << 40);
+}
+
+hipError_t launch_generic_encode(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const uint16_t *d_rect, size_t rect_stride,
+                                 QuantaRef q, const PlaneSetMut &coef)
+{
+    GenEncArgs a{};
+    a.count = L.nplanes; a.W = L.width; a.H = L.height;
+    a.level = ldexpf(1.0f, L.precision - 1) * 8.0f;   // encode.swift:215-218: no +0.5 in the forward level shift
+    a.limit = ldexpf(1.0f, L.precision) - 1.0f;
+    a.rect = d_rect; a.rect_stride = rect_stride;
+    a.quanta = q.d_quanta; a.quanta_stride = q.image_stride;
+    int need_x = 0, need_y = 0;                       // the padded planes, in pixels at the image's scale
+    for (int p = 0; p < L.nplanes; ++p) {
+        GenEncPlane &P = a.pl[p];
+        P.coef = static_cast<int16_t *>(coef.ptr[p]); P.stride = coef.stride[p];
+        P.ux = L.units_x[p]; P.uy = L.units_y[p]; P.qi = L.qi[p];
+        P.rx = L.scale_x / L.factor_x[p]; P.ry = L.scale_y / L.factor_y[p];   // the response of the box, encode.swift:403
+        need_x = max(need_x, 8 * P.ux * P.rx); need_y = max(need_y, 8 * P.uy * P.ry);
+    }
+    if (n_images == 0 || need_x == 0 || need_y == 0) return hipSuccess;
+    // tile height: 32 rows.  64 rows would fill the workgroup better (4:2:0: 192 blocks instead of 96 under 32 rows)
+    int blocks64 = 0;
+    for (int p = 0; p < L.nplanes; ++p) blocks64 += (GEW / (8 * a.pl[p].rx)) * (64 / (8 * a.pl[p].ry));
+    // (measured: 64-row tiles are SLOWER -- 8192 x 8192 12-bit 4:2:0 472 against 403 us, 4:2:2 923 against 490 -- although they fill
+    // the workgroup's lanes: fewer, larger workgroups hide less of each other's barriers.  JA_X_GENERIC_ENCODE_64 builds them.)
+#ifdef JA_X_GENERIC_ENCODE_64
+    const int geh = (L.nplanes <= 3 && blocks64 <= kGThreads) ? 64 : 32;
+#else
+    const int geh = 32;
+    (void)blocks64;
+#endif
+    a.tiles_x = (need_x + GEW - 1) / GEW;
+    const dim3 grid(a.tiles_x * ((need_y + geh - 1) / geh), n_images);
+    size_t tile_bytes = 0;
+    for (int p = 0; p < L.nplanes; ++p) tile_bytes += (size_t)2 * (GEW / a.pl[p].rx) * (geh / a.pl[p].ry);
+#define JA_GE(C_) do { if (geh == 64) hipLaunchKernelGGL((k_generic_encode<C_, 64>), grid, dim3(kGThreads), tile_bytes, stream, a); \
+                       else hipLaunchKernelGGL((k_generic_encode<C_, 32>), grid, dim3(kGThreads), tile_bytes, stream, a); } while (0)
+    switch (L.nplanes) {
+    case 1: JA_GE(1); break;
+    case 2: JA_GE(2); break;
+    case 3: JA_GE(3); break;
+    default: hipLaunchKernelGGL((k_generic_encode<4, 32>), grid, dim3(kGThreads), tile_bytes, stream, a); break;
+    }
+#undef JA_GE
     return hipGetLastError();
 }
 

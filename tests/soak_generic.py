@@ -44,5 +44,13 @@ for it in range(N):
     if not (got == want).all():
         bad += 1
         print("MISMATCH", w, h, n, precision, cosite, [c.factor for c in layout.planes], layout.scale, int((got != want).sum()), flush=True)
+    # ... and back: the interleaved samples through the fused Rectangular -> Spectral (decomposed() + fdct(quanta:))
+    flist = [c.factor for c in layout.planes]
+    enc = J.Rectangular.from_host(ctx, (w, h), layout, want).spectral({c.qi: quanta[c.qi] for c in layout.planes}).host_planes()
+    want_d = O.decompose(want.reshape(h, w, n), (w, h), flist, layout.scale)
+    want_f = [O.fdct_plane(p, quanta[c.qi], precision) for p, c in zip(want_d, layout.planes)]
+    if not all((a == b).all() for a, b in zip(enc, want_f)):
+        bad += 1
+        print("MISMATCH (encode)", w, h, n, precision, flist, layout.scale, [int((a != b).sum()) for a, b in zip(enc, want_f)], flush=True)
 print("generic soak done", N, "cases, mismatches:", bad)
 sys.exit(1 if bad else 0)

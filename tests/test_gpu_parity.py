@@ -564,3 +564,71 @@ def test_generic_fused_batch_strides(J, ctx):
         want_p = [O.idct_plane(host[i][p], tables[i][min(p, 1)], 12) for p in range(3)]
         want = O.interleave(want_p, [(2, 2), (1, 1), (1, 1)], (2, 2), size, cosited=False)
         assert (got[i] == want.reshape(-1)).all(), i
+
+
+@pytest.mark.parametrize("case", range(len(GENERIC_FUSED)))
+def test_generic_fused_encode_matches_oracle_and_staged(J, ctx, case):
+    """jpeg_amd_rectangular_spectral == decomposed().fdct(quanta:) (encode.swift:389-425, 199-248) for custom formats, one launch:
+    against the oracle AND against the staged kernels, on the layouts and sizes of the decode test; samples over the whole range
+    of the precision (the min(limit, .) of encode.swift:85 included: a few samples lie above 2^P - 1)."""
+    size, precision, factors, _cosite = GENERIC_FUSED[case]
+    rng = np.random.default_rng(5200 + case)
+    n = len(factors)
+    comps = {i + 1: J.Component(f, i & 1) for i, f in enumerate(factors)}
+    if case == 6:
+        comps[99] = J.Component((2, 2), 0)
+    layout = J.Layout(("custom", precision, n), comps)
+    w, h = size
+    top = (1 << precision) - 1
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = (0.5 + 0.45 * np.sin(xx / 9.0) * np.cos(yy / 7.0))[..., None] * top
+    values = np.clip(base + rng.integers(-top // 8 - 1, top // 8 + 2, (h, w, n)), 0, 65535).astype(np.uint16)
+    values[rng.integers(0, h, 5), rng.integers(0, w, 5)] = min(65535, top + 3)          # above the limit of the precision
+    quanta = {0: rng.integers(1, 40, 64).astype(np.uint16), 1: rng.integers(1, 40, 64).astype(np.uint16)}
+    rect = J.Rectangular.from_host(ctx, size, layout, values)
+    got = rect.spectral(quanta).host_planes()
+    flist = [c.factor for c in layout.planes]
+    want_d = O.decompose(values, size, flist, layout.scale)
+    want = [O.fdct_plane(p, quanta[c.qi], precision) for p, c in zip(want_d, layout.planes)]
+    for p, (a, b) in enumerate(zip(got, want)):
+        assert (a == b).all(), f"plane {p}: {(a != b).sum()} of {b.size} coefficients differ from the oracle"
+    staged = rect.decomposed().fdct(quanta).host_planes()
+    assert all((a == b).all() for a, b in zip(got, staged))
+
+
+def test_generic_fused_encode_batch_strides_and_host_buffers(J, ctx):
+    """jpeg_amd_rectangular_spectral_batch: three images of one 12-bit 4:2:0 layout, per-image table sets, strides; every image
+    equals the oracle; jpeg_amd_host_rectangular_spectral gives the same planes from host buffers."""
+    import ctypes as C
+    import torch
+    from jpeg_amd import _lib
+    rng = np.random.default_rng(78)
+    size, n = (210, 130), 3
+    layout = J.Layout(("custom", 12, 3), {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    units = layout.units(size)
+    L = layout.c_layout(size, units, [0, 1, 1])
+    values = rng.integers(0, 4096, (n, size[1], size[0], 3)).astype(np.uint16)
+    tables = rng.integers(1, 30, (n, 2, 64)).astype(np.uint16)
+    pad = 40
+    d_rect = torch.zeros((n, size[0] * size[1] * 3 + pad), dtype=torch.int16, device=ctx.torch_device)
+    d_rect[:, :size[0] * size[1] * 3] = torch.from_numpy(values.reshape(n, -1).view(np.int16)).to(ctx.torch_device)
+    d_q = torch.from_numpy(tables.view(np.int16)).to(ctx.torch_device)
+    out = [torch.full((n, 64 * a * b + 64), 99, dtype=torch.int16, device=ctx.torch_device) for a, b in units]
+    st = _lib.lib().jpeg_amd_rectangular_spectral_batch(ctx.handle, C.byref(L), n, d_rect.data_ptr(), size[0] * size[1] * 3 + pad,
+                                                        d_q.data_ptr(), 128, 2, _lib.ptr_array([o.data_ptr() for o in out]),
+                                                        _lib.size_array([64 * a * b + 64 for a, b in units]))
+    assert st == 0
+    factors = [(2, 2), (1, 1), (1, 1)]
+    for i in range(n):
+        want_d = O.decompose(values[i], size, factors, (2, 2))
+        for p in range(3):
+            want = O.fdct_plane(want_d[p], tables[i][min(p, 1)], 12)
+            got = out[p][i].cpu().numpy()
+            assert (got[:want.size] == want.reshape(-1)).all(), (i, p)
+            assert (got[want.size:] == 99).all()
+    h_out = [np.zeros((b, a, 64), np.int16) for a, b in units]
+    st = _lib.lib().jpeg_amd_host_rectangular_spectral(ctx.handle, C.byref(L), values[1].ctypes.data, tables[1].ctypes.data, 2,
+                                                       _lib.ptr_array([o.ctypes.data for o in h_out]))
+    assert st == 0
+    for p in range(3):
+        assert (h_out[p].reshape(-1) == out[p][1].cpu().numpy()[:h_out[p].size]).all()

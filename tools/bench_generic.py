@@ -71,7 +71,18 @@ def run(name, fmt, comps, cosite):
         else:
             line += f" | fused: not supported ({st})"
     mse = timed(staged_encode, args.reps)
-    line += f" | encode staged {mse*1e3:9.1f} us {nbytes/mse/1e6:7.0f} GB/s  [{nbytes/1e6:.0f} MB alg]"
+    line += f" | encode staged {mse*1e3:9.1f} us {nbytes/mse/1e6:7.0f} GB/s"
+    if hasattr(lib, "jpeg_amd_rectangular_spectral"):
+        back2 = [torch.empty_like(b) for b in back]
+        bp2 = _lib.ptr_array([t.data_ptr() for t in back2])
+        def fused_encode():
+            st = lib.jpeg_amd_rectangular_spectral(ctx.handle, C.byref(L), rect.data_ptr(), qptr, 2, bp2)
+            assert st == 0, st
+        fused_encode()
+        same = all(bool(torch.equal(a, b)) for a, b in zip(back, back2))
+        msf = timed(fused_encode, args.reps)
+        line += f" | fused {msf*1e3:9.1f} us {nbytes/msf/1e6:7.0f} GB/s ({mse/msf:4.1f} x, {'== staged' if same else 'DIFFERS'})"
+    line += f"  [{nbytes/1e6:.0f} MB alg]"
     print(line, flush=True)
 
 

@@ -564,8 +564,12 @@ hipError_t launch_generic_encode(hipStream_t stream, int n_images, const jpeg_am
     const dim3 grid(a.tiles_x * ((need_y + geh - 1) / geh), n_images);
     size_t tile_bytes = 0;
     for (int p = 0; p < L.nplanes; ++p) tile_bytes += (size_t)2 * (GEW / a.pl[p].rx) * (geh / a.pl[p].ry);
+#ifdef JA_X_GENERIC_ENCODE_64
 #define JA_GE(C_) do { if (geh == 64) hipLaunchKernelGGL((k_generic_encode<C_, 64>), grid, dim3(kGThreads), tile_bytes, stream, a); \
                        else hipLaunchKernelGGL((k_generic_encode<C_, 32>), grid, dim3(kGThreads), tile_bytes, stream, a); } while (0)
+#else
+#define JA_GE(C_) hipLaunchKernelGGL((k_generic_encode<C_, 32>), grid, dim3(kGThreads), tile_bytes, stream, a)
+#endif
     switch (L.nplanes) {
     case 1: JA_GE(1); break;
     case 2: JA_GE(2); break;

@@ -40,6 +40,41 @@ static int decode(const std::vector<uint8_t> &file, Decoded &d, int threads)
     return jpeg_amd_jpeg_decode_spectral_mt(file.data(), file.size(), ptr, d.quanta, nullptr, threads);
 }
 
+// The sparse output of the same decoder into heap buffers of EXACTLY the sizes passed (the sanitizer sees a write one entry
+// past either), expanded and compared with the planes when both decodes succeed.  capacity_per_block: arena size in entries per block.
+static bool sparse_agrees(const std::vector<uint8_t> &file, const Decoded *planes, int capacity_per_block)
+{
+    jpeg_amd_frame_info fi{};
+    if (jpeg_amd_jpeg_inspect(file.data(), file.size(), &fi) != JPEG_AMD_OK) return true;
+    size_t blocks = 0;
+    for (int c = 0; c < fi.ncomponents; ++c) blocks += (size_t)fi.units_x[c] * fi.units_y[c];
+    if (blocks == 0 || blocks > (1u << 20)) return true;
+    std::vector<uint32_t> desc(blocks), ent(blocks * (size_t)capacity_per_block);
+    uint16_t quanta[JPEG_AMD_MAX_PLANES][64];
+    size_t n = 0;
+    const int st = jpeg_amd_jpeg_decode_sparse(file.data(), file.size(), desc.data(), desc.size(), ent.data(), ent.size(), &n, quanta, nullptr);
+    if (st != JPEG_AMD_OK || !planes) return true;
+    if (n > ent.size()) return false;
+    size_t first = 0;
+    for (int c = 0; c < fi.ncomponents; ++c) {
+        const size_t nb = (size_t)fi.units_x[c] * fi.units_y[c];
+        for (size_t b = 0; b < nb; ++b) {
+            int16_t blk[64] = {0};
+            uint32_t at = desc[first + b];
+            if (at != 0xffffffffu)
+                for (;; ++at) {
+                    if (at >= n) return false;
+                    const uint32_t e = ent[at];
+                    blk[(e >> 16) & 63] = (int16_t)(e & 0xffff);
+                    if (e >> 31) break;
+                }
+            if (std::memcmp(blk, planes->planes[c].data() + 64 * b, 128) != 0) return false;
+        }
+        first += nb;
+    }
+    return true;
+}
+
 static int encode(const Decoded &d, bool progressive, std::vector<uint8_t> &out)
 {
     const int nc = d.fi.ncomponents;
@@ -94,6 +129,7 @@ int main(int argc, char **argv)
         if (st != JPEG_AMD_OK) { std::printf("%s: decode status %d\n", argv[a], st); ++failures; continue; }
         Decoded dm;
         if (decode(file, dm, 4) != JPEG_AMD_OK || dm.planes != d.planes) { std::printf("%s: threaded decode differs\n", argv[a]); ++failures; }
+        if (!sparse_agrees(file, &d, 64) || !sparse_agrees(file, &d, 3)) { std::printf("%s: sparse decode differs\n", argv[a]); ++failures; }
         {   // the same file through the growing-stream decoder, 777 bytes at a time
             jpeg_amd_stream *st2 = jpeg_amd_stream_create();
             int done = 0, fin = 0, bad = 0;
@@ -131,7 +167,11 @@ int main(int argc, char **argv)
                 }
             }
             Decoded junk;
-            (void)decode(bad, junk, it & 1 ? 3 : 1);
+            const int sj = decode(bad, junk, it & 1 ? 3 : 1);
+            // the sparse writer on the same damaged bytes, with a roomy and with a tight arena; where the planes exist it must agree
+            if (!sparse_agrees(bad, sj == JPEG_AMD_OK && (it & 1) == 0 ? &junk : nullptr, it & 2 ? 64 : 2)) {
+                std::printf("%s: sparse decode of a damaged copy differs (iteration %d)\n", argv[a], it); ++failures;
+            }
             if (it % 8 == 0) {   // corrupted bytes through the stream decoder as well
                 jpeg_amd_stream *st3 = jpeg_amd_stream_create();
                 int done = 0, fin = 0;

@@ -409,6 +409,14 @@ int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const
                             const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans,
                             int nscans, const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
                             uint8_t *h_out, size_t out_stride, size_t nbytes[]);
+/* The same with the pixels ALREADY ON THE DEVICE (picture i at d_pixels + i * pixel_stride): nothing is uploaded, the
+ * coefficients come down and the files are written into host memory as above. */
+int jpeg_amd_compress_batch_device(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *d_pixels,
+                            size_t pixel_stride, int n_images, jpeg_amd_color color,
+                            const int32_t *quanta_key, const uint16_t *h_quanta,
+                            const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans,
+                            int nscans, const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
+                            uint8_t *h_out, size_t out_stride, size_t nbytes[]);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,8 @@ SIGNATURES = {
     "jpeg_amd_compress": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_compress_batch": (C.c_int, [_p, _p, _p, C.c_size_t, C.c_int, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int,
                                           C.c_int, _p, C.c_size_t, _p]),
+    "jpeg_amd_compress_batch_device": (C.c_int, [_p, _p, _p, C.c_size_t, C.c_int, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int,
+                                                 C.c_int, _p, C.c_size_t, _p]),
 }
 
 

@@ -1425,15 +1425,19 @@ JA_NOTHROW_TAIL
 
 // ---- many pictures of one geometry -> JPEG files: one fused encode launch per chunk, the host
 //      threads entropy-code the planes of a chunk as soon as they are back ------------------------
-int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels,
-                            size_t pixel_stride, int n_images, jpeg_amd_color color,
-                            const int32_t *quanta_key, const uint16_t *h_quanta, const int32_t *h_quanta_keys,
-                            int ntables, const jpeg_amd_scan *scans, int nscans,
-                            const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
-                            uint8_t *h_out, size_t out_stride, size_t nbytes[])
-try {
+namespace {
+
+// Pixels -> files; the pixels in host memory (h_pixels) or already on the device (d_pixels_in): jpeg_amd_compress_batch[_device].
+int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels, const uint8_t *d_pixels_in,
+                        size_t pixel_stride, int n_images, jpeg_amd_color color,
+                        const int32_t *quanta_key, const uint16_t *h_quanta, const int32_t *h_quanta_keys,
+                        int ntables, const jpeg_amd_scan *scans, int nscans,
+                        const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
+                        uint8_t *h_out, size_t out_stride, size_t nbytes[])
+{
     JA_TRY(bind(ctx));
-    if (!frame || !h_pixels || !quanta_key || !h_quanta || !h_quanta_keys || !scans || !h_out || !nbytes || n_images < 0)
+    const bool on_device = d_pixels_in != nullptr;
+    if (!frame || (!h_pixels && !on_device) || !quanta_key || !h_quanta || !h_quanta_keys || !scans || !h_out || !nbytes || n_images < 0)
         return JPEG_AMD_EINVAL;
     if (n_images == 0) return JPEG_AMD_OK;
     const int nc = frame->ncomponents;
@@ -1476,7 +1480,7 @@ try {
 
     const int nchunks = (n_images + chunk - 1) / chunk;
     // a caller whose pixels are page-locked gets them uploaded from where they are: nothing to stage
-    const bool direct_in = is_pinned_host(h_pixels, (size_t)(n_images - 1) * pixel_stride + npx);
+    const bool direct_in = on_device || is_pinned_host(h_pixels, (size_t)(n_images - 1) * pixel_stride + npx);
     const size_t piece = (size_t)4 << 20, per_image = (npx + piece - 1) / piece;   // pixels are staged in pieces of <= 4 MiB
     // The device side of chunk k, asynchronous: pixels up and kernels on the context's stream, coefficients down on the
     // second one, so that chunk k's download overlaps chunk k + 1's upload.  Device slot and pinned slot k & 1 were last
@@ -1487,12 +1491,15 @@ try {
         char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
         int16_t *d_coef[JPEG_AMD_MAX_PLANES] = {};
         for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<int16_t *>(dev + coef_off[c]);
-        if (!direct_in) JA_HIP(ctx, hipMemcpyAsync(dev, host, npx * m, hipMemcpyHostToDevice, ctx->stream));
+        const uint8_t *d_px = reinterpret_cast<const uint8_t *>(dev);
+        size_t d_px_stride = npx;
+        if (on_device) { d_px = d_pixels_in + (size_t)k * chunk * pixel_stride; d_px_stride = pixel_stride; }   // encoded where they are
+        else if (!direct_in) JA_HIP(ctx, hipMemcpyAsync(dev, host, npx * m, hipMemcpyHostToDevice, ctx->stream));
         else if (pixel_stride == npx) JA_HIP(ctx, hipMemcpyAsync(dev, h_pixels + (size_t)k * chunk * npx, npx * m, hipMemcpyHostToDevice, ctx->stream));
         else
             for (int i = 0; i < m; ++i)
                 JA_HIP(ctx, hipMemcpyAsync(dev + npx * i, h_pixels + ((size_t)k * chunk + i) * pixel_stride, npx, hipMemcpyHostToDevice, ctx->stream));
-        JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, reinterpret_cast<const uint8_t *>(dev), npx, color, d_q, 0, ntables, d_coef, stride));
+        JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, d_px, d_px_stride, color, d_q, 0, ntables, d_coef, stride));
         JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
         JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
         for (int c = 0; c < nc; ++c)
@@ -1544,6 +1551,33 @@ try {
     if (result == JPEG_AMD_OK) result = host_region(nchunks - 1, nchunks);
     if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->file_d2h); }
     return result;
+}
+
+}  // namespace
+
+int jpeg_amd_compress_batch(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *h_pixels,
+                            size_t pixel_stride, int n_images, jpeg_amd_color color,
+                            const int32_t *quanta_key, const uint16_t *h_quanta, const int32_t *h_quanta_keys,
+                            int ntables, const jpeg_amd_scan *scans, int nscans,
+                            const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
+                            uint8_t *h_out, size_t out_stride, size_t nbytes[])
+try {
+    if (!h_pixels) return JPEG_AMD_EINVAL;
+    return compress_batch_impl(ctx, frame, h_pixels, nullptr, pixel_stride, n_images, color, quanta_key, h_quanta, h_quanta_keys, ntables,
+                               scans, nscans, metadata, nmetadata, nthreads, h_out, out_stride, nbytes);
+}
+JA_NOTHROW_TAIL
+
+int jpeg_amd_compress_batch_device(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8_t *d_pixels,
+                                   size_t pixel_stride, int n_images, jpeg_amd_color color,
+                                   const int32_t *quanta_key, const uint16_t *h_quanta, const int32_t *h_quanta_keys,
+                                   int ntables, const jpeg_amd_scan *scans, int nscans,
+                                   const jpeg_amd_metadata *metadata, int nmetadata, int nthreads,
+                                   uint8_t *h_out, size_t out_stride, size_t nbytes[])
+try {
+    if (!d_pixels) return JPEG_AMD_EINVAL;
+    return compress_batch_impl(ctx, frame, nullptr, d_pixels, pixel_stride, n_images, color, quanta_key, h_quanta, h_quanta_keys, ntables,
+                               scans, nscans, metadata, nmetadata, nthreads, h_out, out_stride, nbytes);
 }
 JA_NOTHROW_TAIL
 

@@ -199,3 +199,39 @@ def test_compress_batch_over_several_chunks_pageable_and_pinned_pixels(ctx, pinn
                 want[i] = one[:nb.value].tobytes()
             assert got == want[i], (i, threads)
     assert len(set(want.values())) > 40     # the pictures do differ
+
+
+def test_compress_batch_device_takes_the_pixels_where_they_are(ctx):
+    """jpeg_amd_compress_batch_device: 40 pictures already in device memory (two chunks), with a pitch: the same files as
+    jpeg_amd_compress_batch writes from host memory."""
+    import torch
+    import jpeg_amd as J
+    case = next(c for c in G.encode_cases() if c["mode"] == "4-2-0" and c["level"] == 0.5)
+    rgb, (w, h) = G.encode_source()
+    n = 40
+    stride = w * h * 3 + 16
+    px = np.zeros(n * stride, np.uint8)
+    for i in range(n):
+        px[i * stride:i * stride + w * h * 3] = rgb.reshape(-1)
+        px[i * stride:i * stride + 30] = (i * 5) & 255
+    d_px = torch.from_numpy(px).to(ctx.torch_device)
+    info = _lib.FrameInfo()
+    info.width, info.height, info.precision, info.ncomponents, info.process = w, h, 8, 3, 0
+    for c, (fx, fy) in enumerate(case["factors"]):
+        info.id[c], info.factor_x[c], info.factor_y[c] = c + 1, fx, fy
+    tables = _quanta(case["level"])
+    qkey, tk = (C.c_int32 * 3)(0, 1, 1), (C.c_int32 * 2)(0, 1)
+    sarr = _scan_array(SCANS)
+    marr, nmeta, _keep = _metadata_array(JFIF)
+    cap = 1 << 18
+    lib = _lib.lib()
+    outs = []
+    for fn, src in ((lib.jpeg_amd_compress_batch, px.ctypes.data), (lib.jpeg_amd_compress_batch_device, d_px.data_ptr())):
+        out = np.zeros((n, cap), np.uint8)
+        sizes = (C.c_size_t * n)()
+        st = fn(ctx.handle, C.byref(info), src, stride, n, J.RGB.code, qkey, tables.ctypes.data, tk, 2, sarr, 2, marr, nmeta, 4,
+                out.ctypes.data, cap, sizes)
+        assert st == 0, st
+        outs.append([out[i, :sizes[i]].tobytes() for i in range(n)])
+    assert outs[0] == outs[1]
+    assert len(set(outs[0])) > 20

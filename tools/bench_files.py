@@ -76,3 +76,12 @@ for t in args.threads:
         dt = time.perf_counter() - t0
         assert st == 0, st
     print(f"  compress {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s")
+d_px = torch.from_numpy(px).to(ctx.torch_device)
+for t in args.threads:
+    for rep in range(2):
+        t0 = time.perf_counter()
+        st = lib.jpeg_amd_compress_batch_device(ctx.handle, C.byref(info), d_px.data_ptr(), 0, n, J.RGB.code, qkey, tables.ctypes.data, tk, 2,
+                                                sarr, 2, marr, nmeta, t, jout.ctypes.data, cap, jsizes)
+        dt = time.perf_counter() - t0
+        assert st == 0, st
+    print(f"  compress from device memory {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s")

@@ -388,6 +388,15 @@ int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_
                                   const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out,
                                   size_t capacity,
                                   size_t *nbytes);
+/* The same writer fed with SPARSE coefficients (the format of jpeg_amd_jpeg_decode_sparse: h_desc one descriptor per block of the
+ * frame, planes in frame order; h_entries / nentries the arena; a block's entries in ascending zigzag index, the DC first):
+ * sequential scans only (JPEG_AMD_ENOSUP for a progressive frame).  Byte-identical to jpeg_amd_jpeg_encode_spectral on the
+ * planes those entries expand to.  jpeg_amd_compress_batch brings the coefficients down from the device in this form. */
+int jpeg_amd_jpeg_encode_sparse(const jpeg_amd_frame_info *frame, const int32_t *quanta_key, const uint32_t *h_desc,
+                                const uint32_t *h_entries, size_t nentries, const uint16_t *h_quanta,
+                                const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans, int nscans,
+                                const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out, size_t capacity,
+                                size_t *nbytes);
 /* Rectangular.pack(...).compress(stream:quanta:)  (encode.swift:456, 2031; os.swift:412): H*W
  * colours of 3 bytes in host memory -> colour conversion, downsampling, FDCT and quantisation on
  * the GPU -> entropy coding on the host -> JPEG bytes.  8-bit, 1 or 3 components, ids in

@@ -361,11 +361,68 @@ inline void tokenize_block(const int16_t *blk, int16_t &pred, TokenList &list, l
 struct Plane {
     const int16_t *coef;
     int ux, uy, fx, fy;
+    // the sparse form (jpeg_amd_jpeg_encode_sparse): coef == nullptr, one descriptor per block of THIS plane, the frame's entries
+    const uint32_t *desc = nullptr, *entries = nullptr;
+    size_t nentries = 0;
     const int16_t *at(int x, int y) const
     {
         return (x < ux && y < uy) ? coef + (size_t)64 * ((size_t)ux * y + x) : kZeroBlock;
     }
 };
+
+// tokenize_block for a block given as entries (value, zigzag index, last-of-block flag; ascending index, the DC first):
+// the runs come from the indices, no coefficient is looked at that is zero.  A block outside the plane or without a
+// descriptor is all zero.  Entries that run past the arena, or whose indices do not ascend, end the block (a damaged arena
+// must not be read out of bounds; the file is then simply not the image).
+inline void tokenize_sparse(const Plane &p, int x, int y, int16_t &pred, TokenList &list, long *dc_freq, long *ac_freq, int dc_sel, int ac_sel)
+{
+    uint32_t *t = list.room(70);
+    const uint32_t *const t0 = t;
+    size_t at = (x < p.ux && y < p.uy) ? p.desc[(size_t)p.ux * y + x] : 0xffffffffu;
+    if (at >= p.nentries) at = p.nentries;                       // absent (0xFFFFFFFF) or out of range: no entries
+    int16_t dc = 0;
+    bool more = at < p.nentries;
+    if (more && ((p.entries[at] >> 16) & 63) == 0) {
+        dc = (int16_t)(p.entries[at] & 0xffffu);
+        more = !(p.entries[at] >> 31);
+        ++at;
+    }
+    int binade;
+    unsigned tail;
+    compact((int16_t)(dc - pred), binade, tail);                 // wrapping 16-bit difference
+    pred = dc;
+    ++dc_freq[binade];
+    *t++ = (uint32_t)binade | (uint32_t)binade << 8 | (uint32_t)dc_sel << 13 | tail << 16;
+    const uint32_t ac_table = (uint32_t)(4 + ac_sel) << 13;
+    int prev = 0;
+    while (more && at < p.nentries) {
+        const uint32_t e = p.entries[at++];
+        more = !(e >> 31);
+        const int z = (int)(e >> 16) & 63;
+        const int16_t v = (int16_t)(e & 0xffffu);
+        if (z <= prev) break;
+        if (v == 0) continue;                                    // (a zero is no entry; tolerated)
+        int run = z - prev - 1;
+        if (run >= 16) {
+            ac_freq[0xf0] += run >> 4;
+            *t++ = 0xf0u | ac_table | (uint32_t)(run >> 4) << 16;
+            run &= 15;
+        }
+        compact(v, binade, tail);
+        const int sym = run << 4 | binade;
+        ++ac_freq[sym];
+        *t++ = (uint32_t)sym | (uint32_t)binade << 8 | ac_table | tail << 16;
+        prev = z;
+    }
+    int run = 63 - prev;
+    if (run >= 16) {
+        ac_freq[0xf0] += run >> 4;
+        *t++ = 0xf0u | ac_table | (uint32_t)(run >> 4) << 16;
+        run &= 15;
+    }
+    if (run > 0) { ++ac_freq[0x00]; *t++ = ac_table; }
+    list.n += (size_t)(t - t0);
+}
 
 void put16(std::vector<uint8_t> &o, unsigned v) { o.push_back((uint8_t)(v >> 8)); o.push_back((uint8_t)v); }
 void segment(std::vector<uint8_t> &o, uint8_t marker, const std::vector<uint8_t> &body)
@@ -585,14 +642,17 @@ extern "C" int jpeg_amd_huffman_build(const int64_t freq[256], uint8_t counts[16
     }
 }
 
-extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_t *quanta_key,
-                                             const int16_t *const h_coef[], const uint16_t *h_quanta,
-                                             const int32_t *h_quanta_keys, int ntables,
-                                             const jpeg_amd_scan *scans, int nscans,
-                                             const jpeg_amd_metadata *metadata, int nmetadata,
-                                             uint8_t *h_out, size_t capacity, size_t *nbytes)
-try {
-    if (!frame || !quanta_key || !h_coef || !h_quanta || !h_quanta_keys || !scans || !nbytes) return JPEG_AMD_EINVAL;
+namespace {
+
+// The file writer.  The coefficients come as planes (h_coef) or, for sequential scans, as sparse entries (h_desc + h_entries:
+// jpeg_amd_jpeg_encode_sparse).
+int encode_file(const jpeg_amd_frame_info *frame, const int32_t *quanta_key, const int16_t *const h_coef[], const uint32_t *h_desc,
+                const uint32_t *h_entries, size_t nentries, const uint16_t *h_quanta, const int32_t *h_quanta_keys, int ntables,
+                const jpeg_amd_scan *scans, int nscans, const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out,
+                size_t capacity, size_t *nbytes)
+{
+    const bool sparse = h_desc != nullptr;
+    if (!frame || !quanta_key || (!h_coef && !sparse) || (sparse && !h_entries) || !h_quanta || !h_quanta_keys || !scans || !nbytes) return JPEG_AMD_EINVAL;
     const int nc = frame->ncomponents;
     if (nc < 1 || nc > JPEG_AMD_MAX_PLANES || nscans < 1 || ntables < 1) return JPEG_AMD_EINVAL;
     if (frame->width < 1 || frame->height < 1 || frame->width > 65535 || frame->height > 65535) return JPEG_AMD_EINVAL;
@@ -601,12 +661,16 @@ try {
     if (nmetadata < 0 || (nmetadata > 0 && !metadata)) return JPEG_AMD_EINVAL;
     const bool progressive = frame->process == 2;
 
+    if (sparse && progressive) return JPEG_AMD_ENOSUP;          // progressive scans slice the coefficients by bit: planes only
     std::vector<Plane> planes((size_t)nc);
+    size_t blocks_before = 0;
     for (int c = 0; c < nc; ++c) {
-        if (!h_coef[c] || frame->units_x[c] < 1 || frame->units_y[c] < 1) return JPEG_AMD_EINVAL;
+        if ((!sparse && !h_coef[c]) || frame->units_x[c] < 1 || frame->units_y[c] < 1) return JPEG_AMD_EINVAL;
         if (frame->factor_x[c] < 1 || frame->factor_x[c] > 4 || frame->factor_y[c] < 1 || frame->factor_y[c] > 4) return JPEG_AMD_EINVAL;
         if (c && frame->id[c] <= frame->id[c - 1]) return JPEG_AMD_EINVAL;   // ascending ids = frame header order
-        planes[c] = {h_coef[c], frame->units_x[c], frame->units_y[c], frame->factor_x[c], frame->factor_y[c]};
+        planes[c] = {sparse ? nullptr : h_coef[c], frame->units_x[c], frame->units_y[c], frame->factor_x[c], frame->factor_y[c]};
+        if (sparse) { planes[c].desc = h_desc + blocks_before; planes[c].entries = h_entries; planes[c].nentries = nentries; }
+        blocks_before += (size_t)frame->units_x[c] * frame->units_y[c];
     }
     auto table_of = [&](int key) -> const uint16_t * {
         for (int t = 0; t < ntables; ++t) if (h_quanta_keys[t] == key) return h_quanta + 64 * t;
@@ -753,7 +817,8 @@ try {
                     for (int y = 0; y < p.uy; ++y)
                         for (int x = 0; x < p.ux; ++x) {
                             boundary();
-                            tokenize_block(p.at(x, y), pred[0], tokens, dc_freq[sc.dc[0]], ac_freq[sc.ac[0]], sc.dc[0], sc.ac[0]);
+                            if (sparse) tokenize_sparse(p, x, y, pred[0], tokens, dc_freq[sc.dc[0]], ac_freq[sc.ac[0]], sc.dc[0], sc.ac[0]);
+                            else tokenize_block(p.at(x, y), pred[0], tokens, dc_freq[sc.dc[0]], ac_freq[sc.ac[0]], sc.dc[0], sc.ac[0]);
                         }
                 } else {
                     for (int my = 0; my < mcuy; ++my)
@@ -762,9 +827,12 @@ try {
                             for (int j = 0; j < ns; ++j) {
                                 const Plane &p = planes[sc.component[j]];
                                 for (int by = 0; by < p.fy; ++by)
-                                    for (int bx = 0; bx < p.fx; ++bx)
-                                        tokenize_block(p.at(mx * p.fx + bx, my * p.fy + by), pred[j], tokens, dc_freq[sc.dc[j]],
-                                                       ac_freq[sc.ac[j]], sc.dc[j], sc.ac[j]);
+                                    for (int bx = 0; bx < p.fx; ++bx) {
+                                        if (sparse) tokenize_sparse(p, mx * p.fx + bx, my * p.fy + by, pred[j], tokens, dc_freq[sc.dc[j]],
+                                                                    ac_freq[sc.ac[j]], sc.dc[j], sc.ac[j]);
+                                        else tokenize_block(p.at(mx * p.fx + bx, my * p.fy + by), pred[j], tokens, dc_freq[sc.dc[j]],
+                                                            ac_freq[sc.ac[j]], sc.dc[j], sc.ac[j]);
+                                    }
                             }
                         }
                 }
@@ -804,6 +872,33 @@ try {
     if (!h_out || capacity < out.size()) return h_out ? JPEG_AMD_EINVAL : JPEG_AMD_OK;   // size query with h_out == NULL
     std::memcpy(h_out, out.data(), out.size());
     return JPEG_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" int jpeg_amd_jpeg_encode_spectral(const jpeg_amd_frame_info *frame, const int32_t *quanta_key,
+                                             const int16_t *const h_coef[], const uint16_t *h_quanta,
+                                             const int32_t *h_quanta_keys, int ntables,
+                                             const jpeg_amd_scan *scans, int nscans,
+                                             const jpeg_amd_metadata *metadata, int nmetadata,
+                                             uint8_t *h_out, size_t capacity, size_t *nbytes)
+try {
+    if (!h_coef) return JPEG_AMD_EINVAL;
+    return encode_file(frame, quanta_key, h_coef, nullptr, nullptr, 0, h_quanta, h_quanta_keys, ntables, scans, nscans, metadata, nmetadata,
+                       h_out, capacity, nbytes);
+}
+catch (const std::bad_alloc &) { return JPEG_AMD_ENOMEM; }
+catch (...) { return JPEG_AMD_ENOMEM; }
+
+extern "C" int jpeg_amd_jpeg_encode_sparse(const jpeg_amd_frame_info *frame, const int32_t *quanta_key, const uint32_t *h_desc,
+                                           const uint32_t *h_entries, size_t nentries, const uint16_t *h_quanta,
+                                           const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans, int nscans,
+                                           const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out, size_t capacity,
+                                           size_t *nbytes)
+try {
+    if (!h_desc || !h_entries) return JPEG_AMD_EINVAL;
+    return encode_file(frame, quanta_key, nullptr, h_desc, h_entries, nentries, h_quanta, h_quanta_keys, ntables, scans, nscans, metadata,
+                       nmetadata, h_out, capacity, nbytes);
 }
 catch (const std::bad_alloc &) { return JPEG_AMD_ENOMEM; }
 catch (...) { return JPEG_AMD_ENOMEM; }

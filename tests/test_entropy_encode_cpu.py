@@ -328,3 +328,51 @@ def test_restart_intervals_written_by_the_library_round_trip(ri, kind):
     assert info2.restart_interval == ri
     for a, b in zip(planes, back):
         assert (a == b).all()
+
+
+@pytest.mark.parametrize("name", [n for n in G.decode_names() if "sequential" in n or n.startswith("karlie")])
+def test_writer_fed_with_sparse_coefficients_writes_the_same_file(name):
+    """jpeg_amd_jpeg_encode_sparse == jpeg_amd_jpeg_encode_spectral on the planes the entries expand to: the coefficients of a
+    sequential fixture (decoded both ways) through both writers, interleaved and one scan per component, with restart intervals."""
+    from _sparse import sparse_decode
+    lib = _lib.lib()
+    data = open(G.path(G.entry(name)["file"]), "rb").read()
+    info = _lib.FrameInfo()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    assert lib.jpeg_amd_jpeg_inspect(buf, len(data), C.byref(info)) == 0
+    if info.process == 2:
+        pytest.skip("progressive")
+    nc = info.ncomponents
+    st, desc, ent, quanta = sparse_decode(lib, data, info)
+    assert st == 0
+    planes = [np.zeros((info.units_y[c], info.units_x[c], 64), np.int16) for c in range(nc)]
+    q2 = np.zeros((4, 64), np.uint16)
+    assert lib.jpeg_amd_jpeg_decode_spectral(buf, len(data), _lib.ptr_array([p.ctypes.data for p in planes]), q2.ctypes.data, None) == 0
+    volume = sum(info.factor_x[c] * info.factor_y[c] for c in range(nc))
+    scan_sets = [[[(c, min(c, 1), min(c, 1))] for c in range(nc)]]
+    if nc > 1 and volume <= 10:
+        scan_sets.append([[(c, min(c, 1), min(c, 1)) for c in range(nc)]])
+    tables = np.ascontiguousarray(quanta[:nc])
+    qkey = (C.c_int32 * nc)(*range(nc))
+    tk = (C.c_int32 * nc)(*range(nc))
+    for scans in scan_sets:
+        for ri in (0, 7):
+            f = _lib.FrameInfo()
+            C.memmove(C.byref(f), C.byref(info), C.sizeof(f))
+            f.process = 0 if nc <= 2 or len(scans) == 1 else 1
+            f.process = 1                                         # extended sequential: four table slots, any component count
+            f.restart_interval = ri
+            sarr = _scan_array(scans)
+            outs = []
+            for sparse in (False, True):
+                n = C.c_size_t()
+                out = np.zeros(len(data) * 2 + 65536, np.uint8)
+                if sparse:
+                    st = lib.jpeg_amd_jpeg_encode_sparse(C.byref(f), qkey, desc.ctypes.data, ent.ctypes.data, ent.size, tables.ctypes.data, tk, nc,
+                                                         sarr, len(scans), None, 0, out.ctypes.data, out.size, C.byref(n))
+                else:
+                    st = lib.jpeg_amd_jpeg_encode_spectral(C.byref(f), qkey, _lib.ptr_array([p.ctypes.data for p in planes]), tables.ctypes.data, tk, nc,
+                                                           sarr, len(scans), None, 0, out.ctypes.data, out.size, C.byref(n))
+                assert st == 0, (st, sparse)
+                outs.append(out[:n.value].tobytes())
+            assert outs[0] == outs[1], (name, len(scans), ri)

@@ -1471,20 +1471,34 @@ int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uin
 
     const uint16_t *d_q = nullptr;
     JA_TRY(stage_quanta(ctx, h_quanta, ntables, &d_q));
-    // slot layout (pinned and device alike): [pixels x chunk][coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk]
+    // Sequential scans: the coefficients come down as SPARSE entries (k_sparsify: a descriptor per block + an entry per
+    // nonzero coefficient, an eighth of the planes for a typical picture) and go to the writer in that form
+    // (jpeg_amd_jpeg_encode_sparse); a picture whose entries do not fit its arena comes down as planes, like every picture of a
+    // progressive frame.  Arena: 24 entries per block.
+    const bool sparse_down = frame->process != 2;
+    size_t blocks = 0;
+    for (int c = 0; c < nc; ++c) blocks += (size_t)L.units_x[c] * L.units_y[c];
+    const size_t arena = 24 * blocks, sparse_elems = blocks + arena;           // uint32 per image: [descriptors][entries]
+    // slot layout (pinned and device alike): [pixels x chunk][coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk][sparse x chunk][counts]
     size_t coef_off[JPEG_AMD_MAX_PLANES] = {};
     size_t off = align256(npx * chunk);
     for (int c = 0; c < nc; ++c) { coef_off[c] = off; off += align256(plane[c] * 2 * chunk); }
+    const size_t sparse_off = off;  off += sparse_down ? align256(sparse_elems * 4 * chunk) : 0;
+    const size_t count_off = off;   off += align256((size_t)chunk * 4);
     const size_t slot_bytes = off;
     JA_TRY(ensure_file_staging(ctx, slot_bytes));
+    // (a third event per slot, for this call: the second stage of a chunk's download is complete)
+    hipEvent_t fetched[2] = {nullptr, nullptr};
+    struct Events { hipEvent_t *e; ~Events() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } events{fetched};
+    for (int i = 0; i < 2; ++i) JA_HIP(ctx, hipEventCreateWithFlags(&fetched[i], hipEventDisableTiming));
 
     const int nchunks = (n_images + chunk - 1) / chunk;
     // a caller whose pixels are page-locked gets them uploaded from where they are: nothing to stage
     const bool direct_in = on_device || is_pinned_host(h_pixels, (size_t)(n_images - 1) * pixel_stride + npx);
     const size_t piece = (size_t)4 << 20, per_image = (npx + piece - 1) / piece;   // pixels are staged in pieces of <= 4 MiB
-    // The device side of chunk k, asynchronous: pixels up and kernels on the context's stream, coefficients down on the
-    // second one, so that chunk k's download overlaps chunk k + 1's upload.  Device slot and pinned slot k & 1 were last
-    // used by chunk k - 2, whose download was waited for before its planes were entropy-coded.
+    // The device side of chunk k, asynchronous: pixels up and kernels on the context's stream; on the second stream, behind
+    // them, the first stage of the download -- the entry counts (or, for a progressive frame, the planes).  Device slot and
+    // pinned slot k & 1 were last used by chunk k - 2, whose download was waited for before its files were written.
     auto submit = [&](int k) -> int {
         const int slot = k & 1, m = std::min(chunk, n_images - k * chunk);
         char *host = static_cast<char *>(ctx->file_pinned[slot]);
@@ -1500,26 +1514,59 @@ int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uin
             for (int i = 0; i < m; ++i)
                 JA_HIP(ctx, hipMemcpyAsync(dev + npx * i, h_pixels + ((size_t)k * chunk + i) * pixel_stride, npx, hipMemcpyHostToDevice, ctx->stream));
         JA_TRY(jpeg_amd_encode_batch(ctx, &L, m, d_px, d_px_stride, color, d_q, 0, ntables, d_coef, stride));
+        if (sparse_down) {
+            PlaneSet cs{};
+            for (int c = 0; c < nc; ++c) { cs.ptr[c] = d_coef[c]; cs.stride[c] = stride[c]; }
+            uint32_t *sp = reinterpret_cast<uint32_t *>(dev + sparse_off);
+            JA_HIP(ctx, launch_sparsify(ctx->stream, m, L, cs, sp, sparse_elems, sp + blocks, sparse_elems, (uint32_t)arena,
+                                        reinterpret_cast<uint32_t *>(dev + count_off)));
+        }
         JA_HIP(ctx, hipEventRecord(ctx->file_decoded[slot], ctx->stream));
         JA_HIP(ctx, hipStreamWaitEvent(ctx->file_d2h, ctx->file_decoded[slot], 0));
-        for (int c = 0; c < nc; ++c)
-            JA_HIP(ctx, hipMemcpyAsync(host + coef_off[c], dev + coef_off[c], plane[c] * 2 * m, hipMemcpyDeviceToHost, ctx->file_d2h));
+        if (sparse_down) JA_HIP(ctx, hipMemcpyAsync(host + count_off, dev + count_off, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->file_d2h));
+        else
+            for (int c = 0; c < nc; ++c)
+                JA_HIP(ctx, hipMemcpyAsync(host + coef_off[c], dev + coef_off[c], plane[c] * 2 * m, hipMemcpyDeviceToHost, ctx->file_d2h));
         JA_HIP(ctx, hipEventRecord(ctx->file_done[slot], ctx->file_d2h));
         return JPEG_AMD_OK;
     };
-    // One parallel region of the host threads: the files of chunk `code` are written from its pinned planes (code >= 0, after
-    // its download) and the pixels of chunk `stage` are copied into its pinned slot (stage < nchunks).  The caller's pixels
+    // The second stage of chunk k's download, once its counts are in: per picture the descriptors and the entries in use --
+    // or its planes, where the entries did not fit.  Issued BEFORE chunk k + 1 is submitted, so that it does not queue up
+    // behind that chunk's kernels on the download stream.
+    auto fetch = [&](int k) -> int {
+        const int slot = k & 1, m = std::min(chunk, n_images - k * chunk);
+        char *host = static_cast<char *>(ctx->file_pinned[slot]);
+        char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
+        if (sparse_down) {
+            JA_HIP(ctx, hipEventSynchronize(ctx->file_done[slot]));
+            const uint32_t *count = reinterpret_cast<const uint32_t *>(host + count_off);
+            for (int i = 0; i < m; ++i) {
+                if (count[i] <= arena) {
+                    const size_t at = sparse_off + sparse_elems * 4 * (size_t)i;
+                    JA_HIP(ctx, hipMemcpyAsync(host + at, dev + at, (blocks + count[i]) * 4, hipMemcpyDeviceToHost, ctx->file_d2h));
+                } else {
+                    for (int c = 0; c < nc; ++c)
+                        JA_HIP(ctx, hipMemcpyAsync(host + coef_off[c] + plane[c] * 2 * i, dev + coef_off[c] + plane[c] * 2 * i, plane[c] * 2,
+                                                   hipMemcpyDeviceToHost, ctx->file_d2h));
+                }
+            }
+        }
+        JA_HIP(ctx, hipEventRecord(fetched[slot], ctx->file_d2h));
+        return JPEG_AMD_OK;
+    };
+    // One parallel region of the host threads: the files of chunk `code` are written from what came down into its pinned slot
+    // (code >= 0) and the pixels of chunk `stage` are copied into its pinned slot (stage < nchunks).  The caller's pixels
     // are pageable memory: copying them to pinned memory on all threads and uploading from there is what keeps the upload
     // asynchronous and at the speed of the link.
     WorkerPool pool(std::min(nthreads, 2 * chunk));
-    auto host_region = [&](int code, int stage) -> int {
+    auto host_region = [&](int code, int stage, int fetch_chunk) -> int {
         int m_code = 0, m_stage = 0;
-        const char *planes_host = nullptr;
+        const char *down = nullptr;
         char *stage_host = nullptr;
         if (code >= 0) {
             m_code = std::min(chunk, n_images - code * chunk);
-            JA_HIP(ctx, hipEventSynchronize(ctx->file_done[code & 1]));
-            planes_host = static_cast<const char *>(ctx->file_pinned[code & 1]);
+            JA_HIP(ctx, hipEventSynchronize(fetched[code & 1]));
+            down = static_cast<const char *>(ctx->file_pinned[code & 1]);
         }
         if (stage < nchunks && !direct_in) {
             m_stage = std::min(chunk, n_images - stage * chunk);
@@ -1527,28 +1574,40 @@ int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uin
         }
         std::vector<int> status((size_t)std::max(m_code, 1), JPEG_AMD_OK);
         const int copies = (int)(per_image * (size_t)m_stage);
-        pool.run(m_code + copies, [&](int j) {
+        pool.begin(m_code + copies, [&](int j) {
             if (j < m_code) {
-                const int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
-                for (int c = 0; c < nc; ++c) planes[c] = reinterpret_cast<const int16_t *>(planes_host + coef_off[c]) + plane[c] * j;
                 const size_t image = (size_t)code * chunk + (size_t)j;
-                status[(size_t)j] = jpeg_amd_jpeg_encode_spectral(frame, quanta_key, planes, h_quanta, h_quanta_keys, ntables, scans, nscans,
-                                                                  metadata, nmetadata, h_out + image * out_stride, out_stride, &nbytes[image]);
+                const uint32_t count = sparse_down ? reinterpret_cast<const uint32_t *>(down + count_off)[j] : 0;
+                if (sparse_down && count <= arena) {
+                    const uint32_t *sp = reinterpret_cast<const uint32_t *>(down + sparse_off) + sparse_elems * (size_t)j;
+                    status[(size_t)j] = jpeg_amd_jpeg_encode_sparse(frame, quanta_key, sp, sp + blocks, count, h_quanta, h_quanta_keys, ntables, scans,
+                                                                    nscans, metadata, nmetadata, h_out + image * out_stride, out_stride, &nbytes[image]);
+                } else {
+                    const int16_t *planes[JPEG_AMD_MAX_PLANES] = {};
+                    for (int c = 0; c < nc; ++c) planes[c] = reinterpret_cast<const int16_t *>(down + coef_off[c]) + plane[c] * j;
+                    status[(size_t)j] = jpeg_amd_jpeg_encode_spectral(frame, quanta_key, planes, h_quanta, h_quanta_keys, ntables, scans, nscans,
+                                                                      metadata, nmetadata, h_out + image * out_stride, out_stride, &nbytes[image]);
+                }
             } else {
                 const size_t q = (size_t)(j - m_code), i = q / per_image, lo = (q % per_image) * piece, len = std::min(piece, npx - lo);
                 std::memcpy(stage_host + npx * i + lo, h_pixels + ((size_t)stage * chunk + i) * pixel_stride + lo, len);
             }
         });
+        // while the other threads are at it, this one waits for the kernels of the chunk on the device and starts the second
+        // stage of its download, which then runs beside the rest of the region
+        const int fetched_status = fetch_chunk >= 0 ? fetch(fetch_chunk) : JPEG_AMD_OK;
+        pool.finish();
+        if (fetched_status != JPEG_AMD_OK) return fetched_status;
         for (int st : status) if (st != JPEG_AMD_OK) return st;   // EINVAL with nbytes[i] > out_stride: buffer too small
         return JPEG_AMD_OK;
     };
-    int result = host_region(-1, 0);
+    int result = host_region(-1, 0, -1);
     if (result == JPEG_AMD_OK) result = submit(0);
     for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
-        result = host_region(k - 1, k + 1);                       // ... while the device works on chunk k
+        result = host_region(k - 1, k + 1, k);                    // ... while the device works on chunk k
         if (result == JPEG_AMD_OK && k + 1 < nchunks) result = submit(k + 1);
     }
-    if (result == JPEG_AMD_OK) result = host_region(nchunks - 1, nchunks);
+    if (result == JPEG_AMD_OK) result = host_region(nchunks - 1, nchunks, -1);
     if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->file_d2h); }
     return result;
 }

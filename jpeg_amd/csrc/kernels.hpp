@@ -53,6 +53,11 @@ hipError_t launch_expand_sparse(hipStream_t stream, int n_images, const jpeg_amd
                                 size_t desc_stride, const uint32_t *d_entries, size_t entries_stride, const uint8_t *d_skip,
                                 const PlaneSetMut &coef);
 
+// ... and the planes -> sparse coefficients (for jpeg_amd_jpeg_encode_sparse).  d_cursor: one uint32 per image, on return the
+// number of entries the image has; larger than `capacity`: the image did not fit and its entries are not valid.
+hipError_t launch_sparsify(hipStream_t stream, int n_images, const jpeg_amd_layout &layout, const PlaneSet &coef, uint32_t *d_desc,
+                           size_t desc_stride, uint32_t *d_entries, size_t entries_stride, uint32_t capacity, uint32_t *d_cursor);
+
 // a9 (+ a11/a12): upsample + interleave, written as Rectangular uint16, or colour-converted
 // straight to YCbCr / RGB bytes.  Planes are uint16 (or uint8 when planes_u8).
 hipError_t launch_planar_to_pixels(hipStream_t stream, int n_images,

@@ -341,6 +341,80 @@ __global__ __launch_bounds__(kThreads) void k_fdct_plane(
 
 inline unsigned blocks_for(size_t n) { return (unsigned)((n + kThreads - 1) / kThreads); }
 
+// ---- planes -> sparse coefficients (the device side of jpeg_amd_jpeg_encode_sparse, entropy_encode.cpp) --------------------
+// One block per work-item: its nonzero coefficients -- and the DC in any case -- become entries (value, zigzag index, last-of-
+// block flag), the entries of a workgroup's 256 blocks one run in the image's arena (space drawn from the image's cursor with
+// one atomic per workgroup; the order of the runs is that of the workgroups' arrival -- the descriptors say where a block's
+// entries are).  An image whose entries do not fit `capacity` ends with cursor > capacity: its planes have to come down whole.
+struct SparsifyArgs {
+    const int16_t *coef[JPEG_AMD_MAX_PLANES];
+    size_t coef_stride[JPEG_AMD_MAX_PLANES];
+    uint32_t first[JPEG_AMD_MAX_PLANES + 1];
+    int nplanes;
+    uint32_t *desc;      size_t desc_stride;
+    uint32_t *entries;   size_t entries_stride;
+    uint32_t capacity;
+    uint32_t *cursor;    // per image, zero before the launch
+};
+
+__global__ __launch_bounds__(kThreads) void k_sparsify(SparsifyArgs a)
+{
+    __shared__ uint32_t wave_total[kThreads / 64];
+    __shared__ uint32_t group_base;
+    const int img = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t b = blockIdx.x * kThreads + t;
+    const bool live = b < a.first[a.nplanes];
+    uint32_t w[32];
+    uint32_t count = 0;
+    if (live) {
+        int p = 0;
+#pragma unroll
+        for (int q = 1; q < JPEG_AMD_MAX_PLANES; ++q) p += (q < a.nplanes && b >= a.first[q]);
+        const int16_t *src = a.coef[0];
+        size_t stride = a.coef_stride[0];
+        uint32_t first = a.first[0];
+#pragma unroll
+        for (int q = 1; q < JPEG_AMD_MAX_PLANES; ++q)
+            if (p == q) { src = a.coef[q]; stride = a.coef_stride[q]; first = a.first[q]; }
+        const uint4 *blk = reinterpret_cast<const uint4 *>(src + img * stride + (size_t)(b - first) * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 v = blk[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+        count = 1;                                              // the DC, zero or not
+        if (w[0] >> 16) ++count;
+#pragma unroll
+        for (int i = 1; i < 32; ++i) count += ((w[i] & 0xffffu) != 0) + ((w[i] >> 16) != 0);
+    }
+    // exclusive prefix of `count` over the workgroup: within the wave by shuffles, across the four waves through LDS
+    uint32_t incl = count;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; ++k) { if (k < wave) before += wave_total[k]; total += wave_total[k]; }
+    if (t == 0) group_base = atomicAdd(a.cursor + img, total);
+    __syncthreads();
+    const uint32_t base = group_base;
+    if (!live || base + total > a.capacity) return;             // (every workgroup of an overflowing image may or may not write: the host looks at the cursor)
+    uint32_t at = base + before + incl - count;
+    a.desc[img * a.desc_stride + b] = at;
+    uint32_t *e = a.entries + img * a.entries_stride;
+    uint32_t left = count;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const uint32_t lo = w[i] & 0xffffu, hi = w[i] >> 16;
+        if (lo != 0 || i == 0) { --left; e[at++] = lo | (uint32_t)(2 * i) << 16 | (left == 0 ? 0x80000000u : 0u); }
+        if (hi != 0) { --left; e[at++] = hi | (uint32_t)(2 * i + 1) << 16 | (left == 0 ? 0x80000000u : 0u); }
+    }
+}
+
 // ---- sparse coefficients -> planes (the device side of jpeg_amd_jpeg_decode_sparse, entropy.cpp) -------------------------
 // Eight work-items per block, one 16-byte octet of the block each: they walk the block's entries together (the same address
 // for all eight: one fetch) and keep what falls into their octet; a workgroup writes 32 whole blocks = 4 KiB in a row.
@@ -396,6 +470,27 @@ __global__ __launch_bounds__(kThreads) void k_expand_sparse(ExpandArgs a)
 // =======================================================================================
 // launchers
 // =======================================================================================
+
+hipError_t launch_sparsify(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const PlaneSet &coef, uint32_t *d_desc,
+                           size_t desc_stride, uint32_t *d_entries, size_t entries_stride, uint32_t capacity, uint32_t *d_cursor)
+{
+    SparsifyArgs a{};
+    a.desc = d_desc; a.desc_stride = desc_stride; a.entries = d_entries; a.entries_stride = entries_stride;
+    a.capacity = capacity; a.cursor = d_cursor; a.nplanes = L.nplanes;
+    uint32_t blocks = 0;
+    for (int p = 0; p < L.nplanes; ++p) {
+        a.coef[p] = static_cast<const int16_t *>(coef.ptr[p]); a.coef_stride[p] = coef.stride[p];
+        a.first[p] = blocks;
+        blocks += (uint32_t)L.units_x[p] * (uint32_t)L.units_y[p];
+    }
+    for (int p = L.nplanes; p <= JPEG_AMD_MAX_PLANES; ++p) a.first[p] = blocks;
+    if (blocks == 0 || n_images == 0) return hipSuccess;
+    const hipError_t e = hipMemsetAsync(d_cursor, 0, (size_t)n_images * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    const dim3 grid((blocks + kThreads - 1) / kThreads, n_images);
+    hipLaunchKernelGGL(k_sparsify, grid, dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_expand_sparse(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const uint32_t *d_desc, size_t desc_stride,
                                 const uint32_t *d_entries, size_t entries_stride, const uint8_t *d_skip, const PlaneSetMut &coef)

@@ -235,3 +235,37 @@ def test_compress_batch_device_takes_the_pixels_where_they_are(ctx):
         outs.append([out[i, :sizes[i]].tobytes() for i in range(n)])
     assert outs[0] == outs[1]
     assert len(set(outs[0])) > 20
+
+
+def test_compress_batch_pictures_too_dense_for_the_sparse_download_come_down_as_planes(ctx):
+    """Noise under all-ones tables has ~64 nonzero coefficients per block: more than the 24 per block a picture's arena holds,
+    so its planes come down whole while the smooth picture between two noisy ones comes down as entries -- every file equals
+    what the staged mirror (jpeg_amd_encode + jpeg_amd_jpeg_encode_spectral on the planes) writes."""
+    import jpeg_amd as J
+    rng = np.random.default_rng(99)
+    w, h, n = 200, 136, 5
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = np.clip(128 + 60 * np.sin(xx / 31.0) * np.cos(yy / 17.0), 0, 255).astype(np.uint8)
+    px = np.zeros((n, h, w, 3), np.uint8)
+    for i in range(n):
+        px[i] = rng.integers(0, 256, (h, w, 3)) if i % 2 == 0 else smooth[..., None]
+    layout = J.Layout("ycc8", {1: ((2, 2), 0), 2: ((1, 1), 1), 3: ((1, 1), 1)})
+    ones = {0: np.ones(64, np.uint16), 1: np.ones(64, np.uint16)}
+    want = [J.Rectangular.pack(ctx, (w, h), layout, px[i].reshape(-1, 3), J.RGB).decomposed().fdct(ones).compress(SCANS, metadata=JFIF) for i in range(n)]
+    info = _lib.FrameInfo()
+    info.width, info.height, info.precision, info.ncomponents, info.process = w, h, 8, 3, 0
+    for c, (fx, fy) in enumerate([(2, 2), (1, 1), (1, 1)]):
+        info.id[c], info.factor_x[c], info.factor_y[c] = c + 1, fx, fy
+    tables = np.ones((2, 64), np.uint16)
+    qkey, tk = (C.c_int32 * 3)(0, 1, 1), (C.c_int32 * 2)(0, 1)
+    sarr = _scan_array(SCANS)
+    marr, nmeta, _keep = _metadata_array(JFIF)
+    cap = 1 << 18
+    out = np.zeros((n, cap), np.uint8)
+    sizes = (C.c_size_t * n)()
+    st = _lib.lib().jpeg_amd_compress_batch(ctx.handle, C.byref(info), px.ctypes.data, 0, n, J.RGB.code, qkey, tables.ctypes.data,
+                                            tk, 2, sarr, 2, marr, nmeta, 3, out.ctypes.data, cap, sizes)
+    assert st == 0, st
+    for i in range(n):
+        assert out[i, :sizes[i]].tobytes() == want[i], i
+    assert sizes[0] > 4 * sizes[1]          # the noisy pictures really are dense

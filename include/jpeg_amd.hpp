@@ -208,6 +208,9 @@ class rectangular {
         return rectangular(c, size, std::move(l), std::move(values));
     }
     planar decomposed() const;
+    /// fused decomposed().fdct(quanta:) (encode.swift:389-425, 353-370) for any format: one launch where every plane lies at the
+    /// image's scale or at half of it, the staged kernels otherwise; the same coefficients either way
+    class spectral to_spectral(const quanta_map &quanta) const;
     /// fused pack(...).decomposed().fdct(quanta:)
     static class spectral encode(const context &c, size2 size, layout l, const std::vector<uint8_t> &pixels, color source,
                                  const quanta_map &quanta);
@@ -405,6 +408,20 @@ inline spectral planar::fdct(const quanta_map &quanta) const
     check(jpeg_amd_planar_fdct(ctx->handle(), &l, const_cast<const uint16_t *const *>(in.data()), tables.data(),
                                (int)(tables.size() / 64), op.data()), "jpeg_amd_planar_fdct");
     return spectral(*ctx, size, lay, units, std::move(out), std::move(tables), std::move(q));
+}
+
+inline spectral rectangular::to_spectral(const quanta_map &quanta) const
+{
+    std::vector<uint16_t> tables; std::vector<int> q;
+    detail::resolve_quanta(lay, quanta, tables, q);
+    std::vector<size2> u = lay.units(size);
+    jpeg_amd_layout l = lay.c_layout(size, u, q);
+    std::vector<device_array<int16_t>> out;
+    for (const size2 &b : u) out.emplace_back(*ctx, (size_t)64 * b.x * b.y);
+    auto op = detail::pointers(out);
+    check(jpeg_amd_rectangular_spectral(ctx->handle(), &l, values.data(), tables.data(), (int)(tables.size() / 64), op.data()),
+          "jpeg_amd_rectangular_spectral");
+    return spectral(*ctx, size, lay, std::move(u), std::move(out), std::move(tables), std::move(q));
 }
 
 inline spectral rectangular::encode(const context &c, size2 size, layout l, const std::vector<uint8_t> &pixels, color source,

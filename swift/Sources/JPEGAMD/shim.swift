@@ -493,4 +493,46 @@ extension JPEG.Data.Rectangular
             _ = buffer.initialize(from: planes[p])
         }
     }
+
+    /// `decomposed().fdct(quanta:)` (encode.swift:389-425, 353-370) in ONE call, for ANY `JPEG.Format` -- what
+    /// `Rectangular.compress(stream:quanta:)` runs in front of the entropy coder (encode.swift:2031).  The samples cross the
+    /// link once, the coefficient planes once; formats whose planes lie at the image's scale or at half of it (factors 1 | 2)
+    /// take one launch with no Planar on the device, every other layout the staged kernels.  Same coefficients as the staged chain.
+    public
+    func spectral(quanta:[JPEG.Table.Quantization.Key: [UInt16]]) -> JPEG.Data.Spectral<Format>
+    {
+        // table bookkeeping stays in Swift (decode.swift:2510-2543); only the arithmetic moves
+        var spectral:JPEG.Data.Spectral<Format> = .init(layout: self.layout)
+        spectral.set(quanta: quanta)
+        var l:jpeg_amd_layout = AMD.layout(self.layout, size: self.size,
+            units: self.layout.recognized.indices.map{ _ in (0, 0) },
+            q: spectral.indices.map{ spectral[$0].q })
+        AMD.check(jpeg_amd_layout_units(&l), "jpeg_amd_layout_units")
+        let units:[(x:Int, y:Int)] = withUnsafeBytes(of: l.units_x){ ux in withUnsafeBytes(of: l.units_y){ uy in
+            self.layout.recognized.indices.map
+            {
+                (Int(ux.load(fromByteOffset: 4 * $0, as: Int32.self)), Int(uy.load(fromByteOffset: 4 * $0, as: Int32.self)))
+            }
+        }}
+        let tables:[UInt16]   = AMD.tables(spectral)
+        let ntables:Int32     = .init(spectral.quanta.count)
+        var coef:[[Int16]]    = units.map{ .init(repeating: 0, count: 64 * $0.x * $0.y) }
+        let status:Int32 = AMD.withMutablePointers(&coef)
+        {
+            (out:[UnsafeMutablePointer<Int16>?]) -> Int32 in
+            AMD.withContext
+            {
+                jpeg_amd_host_rectangular_spectral($0, &l, self.values, tables, ntables, out)
+            }
+        }
+        AMD.check(status, "jpeg_amd_host_rectangular_spectral")
+        for (p, values):(Int, [Int16]) in zip(spectral.indices, coef)
+        {
+            spectral[p].set(values: values, units: units[p])
+        }
+        spectral.set(width:  self.size.x)
+        spectral.set(height: self.size.y)
+        spectral.metadata.append(contentsOf: self.metadata)
+        return spectral
+    }
 }

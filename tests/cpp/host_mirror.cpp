@@ -104,8 +104,11 @@ int main(int argc, char **argv)
         // encode the decoded picture again, staged and fused
         const spectral e1 = rectangular::pack(ctx, size, lay, fused, color::rgb).decomposed().fdct(quanta);
         const spectral e2 = rectangular::encode(ctx, size, lay, fused, color::rgb, quanta);
+        // decomposed().fdct(quanta:) in one call (jpeg_amd_rectangular_spectral) == the staged chain
+        const spectral e3 = rectangular::pack(ctx, size, lay, fused, color::rgb).to_spectral(quanta);
         for (int p = 0; p < np; ++p) {
             if (e1.planes[p].host() != e2.planes[p].host()) { std::cerr << "staged and fused encode differ\n"; return 1; }
+            if (e1.planes[p].host() != e3.planes[p].host()) { std::cerr << "to_spectral() differs from decomposed().fdct()\n"; return 1; }
             dump(std::string(argv[2]) + ".coef" + std::to_string(p), e2.planes[p].host());
         }
         // the reference's preconditions come back as exceptions, not aborts

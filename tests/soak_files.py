@@ -45,7 +45,7 @@ for it in range(N):
     scans = [[(0, 0, 0)]] if nc == 1 else ([[(0, 0, 0)], [(1, 1, 1), (2, 1, 1)]] if rng.integers(2) else [[(0, 0, 0), (1, 1, 1), (2, 1, 1)]])
     sarr = _scan_array(scans)
     marr, nmeta, _keep = _metadata_array([("jfif", (2, 2, 1, 1))])
-    cap = 3 * w * h + 4096
+    cap = 12 * (w + 16) * (h + 16) + 8192      # (noise under all-ones tables is larger than its pixels)
     def compress(fn, src, stride):
         out = np.zeros((n, cap), np.uint8); sizes = (C.c_size_t * n)()
         f = _lib.FrameInfo(); C.memmove(C.byref(f), C.byref(info), C.sizeof(f))

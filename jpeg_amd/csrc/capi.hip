@@ -1276,6 +1276,17 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
         const uint8_t *skip = reinterpret_cast<const uint8_t *>(host + skip_off);
         const size_t *used = used_of[slot].data();
         // (like every failure inside this loop it leaves through the common tail below, which waits for both streams)
+        // While the threads are in chunk k: chunk k + 1 goes into the pinned slot of chunk k - 1, which is free when that chunk's
+        // kernels are done (submitted at the end of the last iteration) -- wait for them here, where this thread has nothing
+        // else to do, and open the chunk: a thread that is through with chunk k goes straight on.
+        if (k >= 1 && k + 1 < nchunks) {
+            const hipError_t w = hipEventSynchronize(ctx->file_decoded[(k - 1) & 1]);
+            if (w != hipSuccess) { ctx->last_hip = (int)w; result = JPEG_AMD_EHIP; break; }
+        }
+        if (k + 1 < nchunks) {
+            { std::lock_guard<std::mutex> g(queue.m); queue.open_chunks = std::max(queue.open_chunks, k + 2); }
+            queue.cv.notify_all();
+        }
         {
             std::unique_lock<std::mutex> g(queue.m);
             queue.cv.wait(g, [&] { return queue.left[(size_t)k] == 0; });          // chunk k is decoded
@@ -1345,15 +1356,6 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
                 drain_status = drain(k - 1);   // no helper thread to be had: copy the chunk out here
                 if (drain_status != JPEG_AMD_OK) { result = drain_status; break; }
             }
-        }
-        // chunk k + 1 goes into the pinned slot of chunk k - 1: free when that chunk's kernels are done
-        if (k >= 1 && k + 1 < nchunks) {
-            const hipError_t w = hipEventSynchronize(ctx->file_decoded[(k - 1) & 1]);
-            if (w != hipSuccess) { ctx->last_hip = (int)w; result = JPEG_AMD_EHIP; break; }
-        }
-        if (k + 1 < nchunks) {
-            { std::lock_guard<std::mutex> g(queue.m); queue.open_chunks = std::max(queue.open_chunks, k + 2); }
-            queue.cv.notify_all();
         }
     }
     if (drainer.joinable()) drainer.join();

@@ -677,6 +677,25 @@ def main():
     run(parse())
 
 
+def host_cpus():
+    """CPUs this process may keep busy: the affinity mask, capped by the control group's CPU bandwidth (cpu.max): a container
+    granted 16 CPUs on a 256-thread host is stopped for the rest of the period when 32 threads run flat out."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def extras(J, ctx, d_quanta, q_np, sync, args, workload="c3"):
     """Short side measurements of the other BASELINE.json configurations (N = 1 only)."""
     import numpy as np
@@ -794,7 +813,7 @@ def extras(J, ctx, d_quanta, q_np, sync, args, workload="c3"):
         ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in batch])
         sizes = (C.c_size_t * n)(*[f.size for f in batch])
         pixels = np.empty((n, W * H * 3), np.uint8)
-        threads = min(32, os.cpu_count() or 1)
+        threads = min(32, host_cpus())
         best = None
         for _ in range(3):
             t0 = time.perf_counter()

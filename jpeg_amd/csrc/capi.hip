@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -12,6 +13,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <chrono>
 #include <system_error>
@@ -21,6 +23,94 @@
 #include "kernels.hpp"
 
 using namespace jpeg_amd;
+
+namespace {
+
+// The host threads of the batch file paths, kept in the context between calls and handed one parallel region after the other.
+// (Starting 32 threads per chunk cost more than half of what a chunk of 32 1080p files takes them; starting and ending them
+// per CALL still meant 32 stacks unmapped per call, and an munmap is what the GPU driver's MMU notifier answers by stopping
+// the queues: every other batch of 512 files took 50 instead of 20 ms.)  Items are drawn from a counter (files differ in length); the calling thread works too.  Not re-entrant:
+// one region at a time.
+class WorkerPool {
+public:
+    explicit WorkerPool(int nthreads)
+    {
+        try {
+            threads_.reserve((size_t)std::max(0, nthreads - 1));
+            for (int t = 1; t < nthreads; ++t) threads_.emplace_back([this, t] { work(t - 1); });
+        } catch (...) {      // fewer threads than asked for: the ones that did start (and the caller) do the work
+        }
+    }
+    ~WorkerPool()
+    {
+        finish();
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        go_.notify_all();
+        for (std::thread &t : threads_) t.join();
+    }
+    int size() const { return (int)threads_.size() + 1; }      // the calling thread included
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
+    // fn(i) for i in [0, count); fn does not throw.  begin() hands the region to the workers and returns; finish() has the
+    // calling thread take its share and waits for the rest.
+    // `threads`: how many threads may work on the region, the calling one (in finish()) included; the pool may be larger
+    void begin(int count, std::function<void(int)> fn, int threads = 1 << 30)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = std::move(fn); count_ = std::max(0, count); next_.store(0);
+            limit_ = std::max(0, threads - 1);
+            busy_ = (int)threads_.size();
+            ++generation_;
+            open_ = true;
+        }
+        go_.notify_all();
+    }
+    void finish()
+    {
+        if (!open_) return;
+        for (int i; (i = next_.fetch_add(1)) < count_;) job_(i);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return busy_ == 0; });
+        open_ = false;
+    }
+    void run(int count, std::function<void(int)> fn, int threads = 1 << 30)
+    {
+        begin(count, std::move(fn), threads);
+        finish();
+    }
+
+private:
+    void work(int id)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            int count;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                go_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                count = id < limit_ ? count_ : -1;             // (a thread beyond the region's limit only reports back: it must not draw an item)
+            }
+            if (count >= 0)
+                for (int i; (i = next_.fetch_add(1)) < count;) job_(i);   // (job_ is not touched until every worker has reported back)
+            std::lock_guard<std::mutex> g(m_);
+            if (--busy_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable go_, done_;
+    std::function<void(int)> job_;
+    std::atomic<int> next_{0};
+    int count_ = 0, busy_ = 0, limit_ = 0;
+    bool open_ = false;
+    unsigned long generation_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace
 
 struct jpeg_amd_ctx {
     int device = 0;
@@ -41,6 +131,8 @@ struct jpeg_amd_ctx {
     hipEvent_t file_done[2] = {nullptr, nullptr};     // chunk's pixels are back in pinned memory
     hipEvent_t file_decoded[2] = {nullptr, nullptr};  // chunk's kernels are done (device -> host copy may start)
     hipStream_t file_d2h = nullptr;                   // downloads overlap the next chunk's uploads (full-duplex PCIe)
+    std::unique_ptr<WorkerPool> workers, copiers;     // host threads of the batch file paths: entropy coding; copies out of the pinned slots
+    std::vector<std::vector<uint32_t>> records;       // a sparse record per entropy-decoding thread
 };
 
 namespace {
@@ -180,6 +272,48 @@ int ensure_file_staging(jpeg_amd_ctx *ctx, size_t slot_bytes)
     return JPEG_AMD_OK;
 }
 
+// How many host threads "all cores" means: the hardware's, capped by the CPU bandwidth the process's control group grants
+// (cgroup v2 cpu.max / v1 cfs quota: a container limited to 16 CPUs on a 256-thread host runs 32 busy threads for a few
+// milliseconds and is then stopped until the period ends -- seen as every other batch taking 40 ms longer).
+int default_host_threads()
+{
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    auto read_two = [](const char *path, long long &a, long long &b) -> bool {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return false;
+        char first[32] = {0};
+        const bool ok = std::fscanf(f, "%31s %lld", first, &b) == 2;
+        std::fclose(f);
+        if (!ok || std::strcmp(first, "max") == 0) return false;
+        a = std::atoll(first);
+        return a > 0 && b > 0;
+    };
+    long long quota = 0, period = 0;
+    if (read_two("/sys/fs/cgroup/cpu.max", quota, period)) n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+    else {
+        FILE *q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *p = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (q && p && std::fscanf(q, "%lld", &quota) == 1 && std::fscanf(p, "%lld", &period) == 1 && quota > 0 && period > 0)
+            n = std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period));
+        if (q) std::fclose(q);
+        if (p) std::fclose(p);
+    }
+    return n;
+}
+
+// Wait for an event of the file pipelines by POLLING it (a yield between polls, a short sleep once the wait is long).
+// hipEventSynchronize on an event recorded a millisecond ago sleeps on an interrupt, and on this stack that wake-up takes
+// tens of milliseconds every few calls: a batch of 512 1080p files alternated between 19.5 and 50 ms.
+hipError_t wait_event(hipEvent_t ev)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else std::this_thread::yield();
+    }
+}
+
 // Is [p, p + bytes) page-locked host memory (hipHostMalloc / hipHostRegister) that a copy engine reaches directly?  Then the
 // batch entry points move the caller's buffer itself instead of staging it through their own pinned slots.
 bool is_pinned_host(const void *p, size_t bytes)
@@ -194,84 +328,12 @@ bool is_pinned_host(const void *p, size_t bytes)
     return true;
 }
 
-// The host threads of one batch call, started once and handed one parallel region after the other (a chunk of files to
-// decode, a chunk of planes to entropy-code): starting 32 threads costs more than half of what a chunk of 32 1080p files
-// takes them.  Items are drawn from a counter (files differ in length); the calling thread works too.  Not re-entrant:
-// one region at a time.
-class WorkerPool {
-public:
-    explicit WorkerPool(int nthreads)
-    {
-        try {
-            threads_.reserve((size_t)std::max(0, nthreads - 1));
-            for (int t = 1; t < nthreads; ++t) threads_.emplace_back([this] { work(); });
-        } catch (...) {      // fewer threads than asked for: the ones that did start (and the caller) do the work
-        }
-    }
-    ~WorkerPool()
-    {
-        finish();
-        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
-        go_.notify_all();
-        for (std::thread &t : threads_) t.join();
-    }
-    WorkerPool(const WorkerPool &) = delete;
-    WorkerPool &operator=(const WorkerPool &) = delete;
-    // fn(i) for i in [0, count); fn does not throw.  begin() hands the region to the workers and returns; finish() has the
-    // calling thread take its share and waits for the rest.
-    void begin(int count, std::function<void(int)> fn)
-    {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            job_ = std::move(fn); count_ = std::max(0, count); next_.store(0);
-            busy_ = (int)threads_.size();
-            ++generation_;
-            open_ = true;
-        }
-        go_.notify_all();
-    }
-    void finish()
-    {
-        if (!open_) return;
-        for (int i; (i = next_.fetch_add(1)) < count_;) job_(i);
-        std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [this] { return busy_ == 0; });
-        open_ = false;
-    }
-    void run(int count, std::function<void(int)> fn)
-    {
-        begin(count, std::move(fn));
-        finish();
-    }
-
-private:
-    void work()
-    {
-        unsigned long seen = 0;
-        for (;;) {
-            int count;
-            {
-                std::unique_lock<std::mutex> g(m_);
-                go_.wait(g, [&] { return stop_ || generation_ != seen; });
-                if (stop_) return;
-                seen = generation_;
-                count = count_;
-            }
-            for (int i; (i = next_.fetch_add(1)) < count;) job_(i);   // (job_ is not touched until every worker has reported back)
-            std::lock_guard<std::mutex> g(m_);
-            if (--busy_ == 0) done_.notify_one();
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex m_;
-    std::condition_variable go_, done_;
-    std::function<void(int)> job_;
-    std::atomic<int> next_{0};
-    int count_ = 0, busy_ = 0;
-    bool open_ = false;
-    unsigned long generation_ = 0;
-    bool stop_ = false;
-};
+// the context's pool, with at least `threads` threads (the calling one included)
+WorkerPool &pool_with(std::unique_ptr<WorkerPool> &pool, int threads)
+{
+    if (!pool || pool->size() < threads) pool.reset(new WorkerPool(threads));
+    return *pool;
+}
 
 // fn(i) for i in [0, m) on up to `nthreads` threads; the calling thread takes a share, and the share of a worker that
 // cannot be started as well (fn does not throw)
@@ -357,6 +419,8 @@ int jpeg_amd_ctx_destroy(jpeg_amd_ctx *ctx)
     if (!ctx) return JPEG_AMD_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->workers.reset();
+    ctx->copiers.reset();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_qstage) (void)hipFree(ctx->d_qstage);
     if (ctx->d_walk) (void)hipFree(ctx->d_walk);
@@ -1139,41 +1203,62 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
     // fit its arena, a progressive or a damaged one is decoded into planes as before and uploaded whole.
     // Arena: 24 entries per block (3/4 of the planes' bytes at most; only what is used is uploaded).
     const size_t arena = 24 * blocks, sparse_elems = blocks + arena;           // uint32 per image: [descriptors][entries]
-    // slot layout: [coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk][quanta x chunk][sparse x chunk][skip flags][pixels x chunk]
+    // slot layout: [coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk] [quanta x chunk][skip flags][record offsets][records ...] [pixels x chunk]
+    // The middle part goes up in ONE copy per chunk: the tables, the per-image flags, where each image's sparse record
+    // [descriptors][entries in use] begins, and the records themselves, packed one behind the other in the order the threads
+    // finish (a copy per image is 32 more commands per chunk, and every ~2 000 commands the runtime stops for 30 ms).
     size_t off = 0;
     for (int c = 0; c < nc; ++c) { coef_off[c] = off; off += align256(plane[c] * 2 * chunk); }
     const size_t quanta_off = off;  off += align256((size_t)chunk * kQSlotElems * 2);
-    const size_t sparse_off = off;  off += align256(sparse_elems * 4 * chunk);
     const size_t skip_off = off;    off += align256((size_t)chunk);
+    const size_t where_off = off;   off += align256((size_t)chunk * 8);
+    const size_t sparse_off = off;  off += align256(sparse_elems * 4 * chunk);
     const size_t px_off = off;      off += to_host ? align256(npx * chunk) : 0;
     const size_t slot_bytes = off;
     JA_TRY(ensure_file_staging(ctx, slot_bytes));
     const bool auto_threads = nthreads <= 0;
-    if (auto_threads) nthreads = (int)std::thread::hardware_concurrency();
+    if (auto_threads) nthreads = default_host_threads();
     nthreads = std::max(1, nthreads);
-
-    auto parallel = [&](int m, auto &&fn) { run_parallel(nthreads, m, fn); };   // (the copy out: on its own threads, beside the pool)
 
     const int nchunks = (n_images + chunk - 1) / chunk;
     int result = JPEG_AMD_OK;
     // a caller whose pixel buffer is page-locked gets the download straight into it: no copy out of the pinned slot
     const bool direct_out = to_host && is_pinned_host(h_pixels, (size_t)(n_images - 1) * pixel_stride + npx);
-    auto drain = [&](int k) -> int {                         // chunk k is on its way back: copy it out
+    const bool copies_out = to_host && !direct_out;
+    // Chunk k on its way back: its pixels are copied out of the pinned slot by the context's copy threads (pieces of <= 8 MiB, so
+    // that one huge image is shared by the threads too) once the download is complete -- the first thread to get there waits for
+    // it, the others for that thread.  begin_drain returns at once; end_drain waits (the calling thread copies too).
+    WorkerPool *copiers = copies_out ? &pool_with(ctx->copiers, std::min(nthreads, 16) + 1) : nullptr;
+    std::atomic<int> arrived{0};                             // 0: nobody has looked yet, 1: a thread is waiting, 2: the pixels are there, 3: failed
+    bool draining = false;
+    auto begin_drain = [&](int k) {
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
-        JA_HIP(ctx, hipEventSynchronize(ctx->file_done[slot]));
-        if (direct_out || !to_host) return JPEG_AMD_OK;
         const uint8_t *src = static_cast<const uint8_t *>(ctx->file_pinned[slot]) + px_off;
-        // copy out in pieces of <= 8 MiB so that one huge image is shared by the threads too
         const size_t piece = (size_t)8 << 20, per_image = (npx + piece - 1) / piece;
-        parallel((int)(per_image * m), [&](int j) {
+        arrived.store(0);
+        draining = true;
+        hipEvent_t done = ctx->file_done[slot];
+        const int device = ctx->device;
+        copiers->begin((int)(per_image * m), [=, &arrived](int j) {
+            int zero = 0;
+            if (arrived.compare_exchange_strong(zero, 1)) {
+                (void)hipSetDevice(device);
+                arrived.store(wait_event(done) == hipSuccess ? 2 : 3);
+            }
+            while (arrived.load() < 2) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (arrived.load() != 2) return;
             const size_t i = (size_t)j / per_image, lo = ((size_t)j % per_image) * piece, len = std::min(piece, npx - lo);
             std::memcpy(h_pixels + (size_t)(base + i) * pixel_stride + lo, src + npx * i + lo, len);
-        });
+        }, std::min(nthreads, 16) + 1);
+    };
+    auto end_drain = [&]() -> int {
+        if (!draining) return JPEG_AMD_OK;
+        copiers->finish();
+        draining = false;
+        if (arrived.load() != 2) { ctx->last_hip = (int)hipErrorUnknown; return JPEG_AMD_EHIP; }
         return JPEG_AMD_OK;
     };
-    struct Joining { std::thread t; ~Joining() { if (t.joinable()) t.join(); } } drainer_owner;   // joined on every way out
-    std::thread &drainer = drainer_owner.t;
-    int drain_status = JPEG_AMD_OK;
+    struct DrainGuard { decltype(end_drain) &f; ~DrainGuard() { (void)f(); } } drain_guard{end_drain};   // joined on every way out
     std::vector<size_t> used_of[2] = {std::vector<size_t>((size_t)chunk, 0), std::vector<size_t>((size_t)chunk, 0)};   // per slot: entries of image i (sparse images)
     std::vector<int> status_all((size_t)n_images, JPEG_AMD_OK);
     // The entropy decoding: ONE queue of files for the whole call.  A host thread takes the next file, waits (rarely) until the
@@ -1194,7 +1279,9 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
     queue.left.resize((size_t)nchunks);
     for (int k = 0; k < nchunks; ++k) queue.left[(size_t)k] = std::min(chunk, n_images - k * chunk);
     std::atomic<int> next_file{0};
-    auto decode_file = [&](int file) -> int {
+    std::atomic<size_t> packed_end[2];                       // per slot: elements of the records packed so far
+    packed_end[0].store(0); packed_end[1].store(0);
+    auto decode_file = [&](int file, std::vector<uint32_t> &record) -> int {
         const int k = file / chunk, i = file - k * chunk, slot = k & 1, m = std::min(chunk, n_images - k * chunk);
         char *host = static_cast<char *>(ctx->file_pinned[slot]);
         uint8_t *skip = reinterpret_cast<uint8_t *>(host + skip_off);
@@ -1220,11 +1307,15 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
         // (spare threads only help a file that has restart intervals; such a file is decoded into planes on `inner` threads)
         bool sparse_done = false;
         if (inner == 1 || fi.restart_interval == 0) {
-            uint32_t *sp = reinterpret_cast<uint32_t *>(host + sparse_off) + sparse_elems * (size_t)i;
+            if (record.size() < sparse_elems) record.resize(sparse_elems);      // (this thread's, for the whole call)
             size_t n = 0;
-            const int ss = jpeg_amd_jpeg_decode_sparse(h_jpeg[file], nbytes[file], sp, blocks, sp + blocks, arena, &n, quanta, &f);
+            const int ss = jpeg_amd_jpeg_decode_sparse(h_jpeg[file], nbytes[file], record.data(), blocks, record.data() + blocks, arena, &n, quanta, &f);
             if (ss == JPEG_AMD_OK) {
                 if (!same_geometry()) return JPEG_AMD_EINVAL;
+                // the record goes behind the ones already in the slot (m records of at most sparse_elems always fit)
+                const size_t at = packed_end[slot].fetch_add(blocks + n);
+                std::memcpy(reinterpret_cast<uint32_t *>(host + sparse_off) + at, record.data(), (blocks + n) * 4);
+                reinterpret_cast<uint64_t *>(host + where_off)[i] = at;
                 skip[i] = 0; used_of[slot][(size_t)i] = n;
                 sparse_done = true;
             } else if (ss != JPEG_AMD_ENOSUP) {
@@ -1240,7 +1331,7 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
             st = jpeg_amd_jpeg_decode_spectral_mt(h_jpeg[file], nbytes[file], planes, quanta, nullptr, inner > 1 && auto_threads ? 0 : inner);
         return st;
     };
-    auto worker = [&]() {
+    auto worker = [&](std::vector<uint32_t> &record) {
         for (;;) {
             const int file = next_file.fetch_add(1);
             if (file >= n_images) return;
@@ -1251,39 +1342,39 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
                 if (queue.abort) return;
             }
             int st;
-            try { st = decode_file(file); } catch (...) { st = JPEG_AMD_ENOMEM; }
+            try { st = decode_file(file, record); } catch (...) { st = JPEG_AMD_ENOMEM; }
             status_all[(size_t)file] = st;
             std::lock_guard<std::mutex> g(queue.m);
             if (--queue.left[(size_t)k] == 0) queue.cv.notify_all();
         }
     };
-    struct Workers {      // joined on every way out, after telling them to stop
-        Queue &q; std::vector<std::thread> t;
-        ~Workers() { { std::lock_guard<std::mutex> g(q.m); q.abort = true; } q.cv.notify_all(); for (std::thread &x : t) x.join(); }
-    } workers{queue, {}};
-    {
-        const int t_n = std::min(nthreads, n_images);
-        try {
-            workers.t.reserve((size_t)t_n);
-            for (int t = 0; t < t_n; ++t) workers.t.emplace_back(worker);
-        } catch (...) {
-        }
-        if (workers.t.empty()) return JPEG_AMD_ENOMEM;      // not one thread to be had
+    const int t_n = std::min(nthreads, n_images);
+    WorkerPool &pool = pool_with(ctx->workers, t_n + 1);     // t_n threads beside this one, which only directs
+    if (ctx->records.size() < (size_t)t_n) ctx->records.resize((size_t)t_n);
+    struct Stop {             // on every way out: tell the threads to stop, wait for them
+        Queue &q; WorkerPool &p;
+        ~Stop() { { std::lock_guard<std::mutex> g(q.m); q.abort = true; } q.cv.notify_all(); p.finish(); }
+    } stop{queue, pool};
+    pool.begin(t_n, [&](int index) { worker(ctx->records[(size_t)index]); }, t_n + 1);
+    if (pool.size() < 2) {                                   // not one thread to be had: this one decodes everything first
+        { std::lock_guard<std::mutex> g(queue.m); queue.open_chunks = nchunks; }
+        if (nchunks > 2) return JPEG_AMD_ENOMEM;             // (only two slots: more than two chunks need a second thread)
+        pool.finish();
     }
     for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
         char *host = static_cast<char *>(ctx->file_pinned[slot]);
         const uint8_t *skip = reinterpret_cast<const uint8_t *>(host + skip_off);
-        const size_t *used = used_of[slot].data();
         // (like every failure inside this loop it leaves through the common tail below, which waits for both streams)
         // While the threads are in chunk k: chunk k + 1 goes into the pinned slot of chunk k - 1, which is free when that chunk's
         // kernels are done (submitted at the end of the last iteration) -- wait for them here, where this thread has nothing
         // else to do, and open the chunk: a thread that is through with chunk k goes straight on.
         if (k >= 1 && k + 1 < nchunks) {
-            const hipError_t w = hipEventSynchronize(ctx->file_decoded[(k - 1) & 1]);
+            const hipError_t w = wait_event(ctx->file_decoded[(k - 1) & 1]);
             if (w != hipSuccess) { ctx->last_hip = (int)w; result = JPEG_AMD_EHIP; break; }
         }
         if (k + 1 < nchunks) {
+            if (k >= 1) packed_end[(k + 1) & 1].store(0);     // (chunks 0 and 1 start from the initial zeros)
             { std::lock_guard<std::mutex> g(queue.m); queue.open_chunks = std::max(queue.open_chunks, k + 2); }
             queue.cv.notify_all();
         }
@@ -1292,7 +1383,13 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
             queue.cv.wait(g, [&] { return queue.left[(size_t)k] == 0; });          // chunk k is decoded
         }
         for (int i = 0; i < m; ++i) if (status_all[(size_t)(base + i)] != JPEG_AMD_OK) result = status_all[(size_t)(base + i)];
-        if (drainer.joinable()) { drainer.join(); if (drain_status != JPEG_AMD_OK) result = drain_status; }
+        { const int ds = end_drain(); if (ds != JPEG_AMD_OK) result = ds; }   // chunk k - 1 is out of its pinned slot: chunk k + 1's download may land there
+        // (downloads that go straight into the caller's buffer are not waited for by a copy out: the device slot's pixels of
+        // chunk k - 2 must have left before chunk k's kernels write there)
+        if (result == JPEG_AMD_OK && direct_out && k >= 2) {
+            const hipError_t w = wait_event(ctx->file_done[slot]);
+            if (w != hipSuccess) { ctx->last_hip = (int)w; result = JPEG_AMD_EHIP; }
+        }
         if (result != JPEG_AMD_OK) break;
         // the device side of chunk k (asynchronous); the host moves on to chunk k + 1 meanwhile.
         // Device slot `slot` was last read by the download of chunk k - 2, finished before drain(k - 2)
@@ -1304,29 +1401,22 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
             for (int c = 0; c < nc; ++c) d_coef[c] = reinterpret_cast<int16_t *>(dev + coef_off[c]);
             size_t stride[JPEG_AMD_MAX_PLANES] = {};
             for (int c = 0; c < nc; ++c) stride[c] = plane[c];
-            bool any_sparse = false, all_dense = true;
-            for (int i = 0; i < m; ++i) { any_sparse = any_sparse || !skip[i]; all_dense = all_dense && skip[i]; }
-            if (all_dense) {
-                for (int c = 0; c < nc; ++c)
-                    JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c], host + coef_off[c], plane[c] * 2 * m, hipMemcpyHostToDevice, ctx->stream));
-            } else {
-                for (int i = 0; i < m; ++i) {
-                    if (skip[i]) {                          // planes, this image only
-                        for (int c = 0; c < nc; ++c)
-                            JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c] + plane[c] * 2 * i, host + coef_off[c] + plane[c] * 2 * i, plane[c] * 2,
-                                                       hipMemcpyHostToDevice, ctx->stream));
-                    } else {                                // descriptors + the entries in use
-                        const size_t at = sparse_off + sparse_elems * 4 * (size_t)i;
-                        JA_HIP(ctx, hipMemcpyAsync(dev + at, host + at, (blocks + used[i]) * 4, hipMemcpyHostToDevice, ctx->stream));
-                    }
-                }
-                JA_HIP(ctx, hipMemcpyAsync(dev + skip_off, host + skip_off, (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+            bool any_sparse = false;
+            for (int i = 0; i < m; ++i) {
+                any_sparse = any_sparse || !skip[i];
+                if (skip[i])                                 // planes, this image only (progressive, damaged, too dense)
+                    for (int c = 0; c < nc; ++c)
+                        JA_HIP(ctx, hipMemcpyAsync(dev + coef_off[c] + plane[c] * 2 * i, host + coef_off[c] + plane[c] * 2 * i, plane[c] * 2,
+                                                   hipMemcpyHostToDevice, ctx->stream));
             }
-            JA_HIP(ctx, hipMemcpyAsync(dev + quanta_off, host + quanta_off, (size_t)m * kQSlotElems * 2, hipMemcpyHostToDevice, ctx->stream));
-            if (any_sparse)
-                JA_TRY(jpeg_amd_spectral_expand_batch(ctx, &L, m, reinterpret_cast<const uint32_t *>(dev + sparse_off), sparse_elems,
-                                                      reinterpret_cast<const uint32_t *>(dev + sparse_off) + blocks, sparse_elems,
-                                                      reinterpret_cast<const uint8_t *>(dev + skip_off), d_coef, stride));
+            // tables, flags, record offsets and the packed records: one copy
+            JA_HIP(ctx, hipMemcpyAsync(dev + quanta_off, host + quanta_off, sparse_off - quanta_off + packed_end[slot].load() * 4, hipMemcpyHostToDevice, ctx->stream));
+            if (any_sparse) {
+                PlaneSetMut cs{};
+                for (int c = 0; c < nc; ++c) { cs.ptr[c] = d_coef[c]; cs.stride[c] = stride[c]; }
+                JA_HIP(ctx, launch_expand_sparse(ctx->stream, m, L, reinterpret_cast<const uint32_t *>(dev + sparse_off), 0, nullptr, 0,
+                                                 reinterpret_cast<const uint8_t *>(dev + skip_off), cs, reinterpret_cast<const uint64_t *>(dev + where_off)));
+            }
             uint8_t *d_px = to_host ? reinterpret_cast<uint8_t *>(dev + px_off) : d_pixels_out + (size_t)base * pixel_stride;
             JA_TRY(jpeg_amd_decode_batch(ctx, &L, m, d_coef, stride, reinterpret_cast<const uint16_t *>(dev + quanta_off), kQSlotElems,
                                          JPEG_AMD_MAX_PLANES, cosited, color, d_px, to_host ? npx : pixel_stride));
@@ -1346,22 +1436,15 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
         };
         result = submit();
         if (result != JPEG_AMD_OK) break;
-        // chunk k - 1 is copied out by a helper thread WHILE the host decodes chunk k + 1; it has
+        // chunk k - 1 is copied out by the copy threads WHILE the others decode chunk k + 1; it has
         // to be finished before chunk k + 1 is submitted (its download lands in the same pinned slot)
-        if (k >= 1) {
-            drain_status = JPEG_AMD_OK;
-            try {
-                drainer = std::thread([&, k] { (void)hipSetDevice(ctx->device); drain_status = drain(k - 1); });
-            } catch (const std::system_error &) {
-                drain_status = drain(k - 1);   // no helper thread to be had: copy the chunk out here
-                if (drain_status != JPEG_AMD_OK) { result = drain_status; break; }
-            }
-        }
+        if (k >= 1 && copies_out) begin_drain(k - 1);
     }
-    if (drainer.joinable()) drainer.join();
-    if (result == JPEG_AMD_OK) result = drain_status;
+    { const int ds = end_drain(); if (result == JPEG_AMD_OK) result = ds; }
     if (result != JPEG_AMD_OK) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamSynchronize(ctx->file_d2h); return result; }
-    JA_TRY(drain(nchunks - 1));
+    // the last chunk: wait for it (and for everything before it on the download stream), copy it out
+    JA_HIP(ctx, wait_event(ctx->file_done[(nchunks - 1) & 1]));
+    if (copies_out) { begin_drain(nchunks - 1); JA_TRY(end_drain()); }
     return JPEG_AMD_OK;
 }
 
@@ -1468,7 +1551,7 @@ int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uin
         plane[c] = stride[c] = (size_t)64 * L.units_x[c] * L.units_y[c];
     }
     const int chunk = std::min(n_images, 32);
-    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = default_host_threads();
     nthreads = std::max(1, nthreads);
 
     const uint16_t *d_q = nullptr;
@@ -1540,7 +1623,7 @@ int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uin
         char *host = static_cast<char *>(ctx->file_pinned[slot]);
         char *dev = static_cast<char *>(ctx->file_device) + (size_t)slot * slot_bytes;
         if (sparse_down) {
-            JA_HIP(ctx, hipEventSynchronize(ctx->file_done[slot]));
+            JA_HIP(ctx, wait_event(ctx->file_done[slot]));
             const uint32_t *count = reinterpret_cast<const uint32_t *>(host + count_off);
             for (int i = 0; i < m; ++i) {
                 if (count[i] <= arena) {
@@ -1560,14 +1643,15 @@ int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uin
     // (code >= 0) and the pixels of chunk `stage` are copied into its pinned slot (stage < nchunks).  The caller's pixels
     // are pageable memory: copying them to pinned memory on all threads and uploading from there is what keeps the upload
     // asynchronous and at the speed of the link.
-    WorkerPool pool(std::min(nthreads, 2 * chunk));
+    WorkerPool &pool = pool_with(ctx->workers, std::min(nthreads, 2 * chunk));   // (kept in the context between calls)
+    struct Finish { WorkerPool &p; ~Finish() { p.finish(); } } finish_on_exit{pool};
     auto host_region = [&](int code, int stage, int fetch_chunk) -> int {
         int m_code = 0, m_stage = 0;
         const char *down = nullptr;
         char *stage_host = nullptr;
         if (code >= 0) {
             m_code = std::min(chunk, n_images - code * chunk);
-            JA_HIP(ctx, hipEventSynchronize(fetched[code & 1]));
+            JA_HIP(ctx, wait_event(fetched[code & 1]));
             down = static_cast<const char *>(ctx->file_pinned[code & 1]);
         }
         if (stage < nchunks && !direct_in) {
@@ -1594,7 +1678,7 @@ int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uin
                 const size_t q = (size_t)(j - m_code), i = q / per_image, lo = (q % per_image) * piece, len = std::min(piece, npx - lo);
                 std::memcpy(stage_host + npx * i + lo, h_pixels + ((size_t)stage * chunk + i) * pixel_stride + lo, len);
             }
-        });
+        }, nthreads);
         // while the other threads are at it, this one waits for the kernels of the chunk on the device and starts the second
         // stage of its download, which then runs beside the rest of the region
         const int fetched_status = fetch_chunk >= 0 ? fetch(fetch_chunk) : JPEG_AMD_OK;

@@ -48,10 +48,11 @@ hipError_t launch_idct_plane(hipStream_t stream, int n_images, const int16_t *d_
                              bool out_u8);
 
 // Sparse coefficients (entropy.cpp, jpeg_amd_jpeg_decode_sparse) -> the planes.  d_skip: optional per-image flags, nonzero =
-// leave that image's planes alone.
+// leave that image's planes alone.  d_packed (optional): the images' records [descriptors][entries] lie packed in d_desc, image i's
+// at element d_packed[i] (the strides and d_entries are then not used).
 hipError_t launch_expand_sparse(hipStream_t stream, int n_images, const jpeg_amd_layout &layout, const uint32_t *d_desc,
                                 size_t desc_stride, const uint32_t *d_entries, size_t entries_stride, const uint8_t *d_skip,
-                                const PlaneSetMut &coef);
+                                const PlaneSetMut &coef, const uint64_t *d_packed = nullptr);
 
 // ... and the planes -> sparse coefficients (for jpeg_amd_jpeg_encode_sparse).  d_cursor: one uint32 per image, on return the
 // number of entries the image has; larger than `capacity`: the image did not fit and its entries are not valid.

@@ -424,6 +424,7 @@ struct ExpandArgs {
     const uint32_t *desc;      size_t desc_stride;       // per image: one descriptor per block, planes in frame order
     const uint32_t *entries;   size_t entries_stride;    // per image: the entry arena
     const uint8_t *skip;                                 // optional, per image
+    const uint64_t *packed;                              // optional, per image: where in `desc` its record [descriptors][entries] begins (elements)
     int16_t *coef[JPEG_AMD_MAX_PLANES];
     size_t coef_stride[JPEG_AMD_MAX_PLANES];
     uint32_t first[JPEG_AMD_MAX_PLANES + 1];             // first[p]: blocks of the planes before p
@@ -441,9 +442,10 @@ __global__ __launch_bounds__(kThreads) void k_expand_sparse(ExpandArgs a)
 #pragma unroll
     for (int q = 1; q < JPEG_AMD_MAX_PLANES; ++q) p += (q < a.nplanes && b >= a.first[q]);
     uint32_t w[4] = {0, 0, 0, 0};
-    uint32_t at = a.desc[img * a.desc_stride + b];
+    const uint32_t *desc = a.packed ? a.desc + a.packed[img] : a.desc + img * a.desc_stride;
+    uint32_t at = desc[b];
     if (at != 0xffffffffu) {
-        const uint32_t *e = a.entries + img * a.entries_stride;
+        const uint32_t *e = a.packed ? desc + a.first[a.nplanes] : a.entries + img * a.entries_stride;
         for (;; ++at) {
             const uint32_t v = e[at];
             const uint32_t pos = (v >> 16) & 63;
@@ -493,10 +495,12 @@ hipError_t launch_sparsify(hipStream_t stream, int n_images, const jpeg_amd_layo
 }
 
 hipError_t launch_expand_sparse(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const uint32_t *d_desc, size_t desc_stride,
-                                const uint32_t *d_entries, size_t entries_stride, const uint8_t *d_skip, const PlaneSetMut &coef)
+                                const uint32_t *d_entries, size_t entries_stride, const uint8_t *d_skip, const PlaneSetMut &coef,
+                                const uint64_t *d_packed)
 {
     ExpandArgs a{};
     a.desc = d_desc; a.desc_stride = desc_stride; a.entries = d_entries; a.entries_stride = entries_stride; a.skip = d_skip;
+    a.packed = d_packed;
     a.nplanes = L.nplanes;
     uint32_t blocks = 0;
     for (int p = 0; p < L.nplanes; ++p) {

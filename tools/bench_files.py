@@ -8,9 +8,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import jpeg_amd as J
 from jpeg_amd import _lib
-ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=256); ap.add_argument("--threads", type=int, nargs="*", default=[1, 8, 32, 64]); ap.add_argument("--pinned", action="store_true", help="the caller's pixel buffers are page-locked: no staging copy")
+ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=256); ap.add_argument("--threads", type=int, nargs="*", default=[1, 8, 16, 32]); ap.add_argument("--pinned", action="store_true", help="the caller's pixel buffers are page-locked: no staging copy")
 args = ap.parse_args()
 ctx = J.Context(0); lib = _lib.lib()
+def timed(call, reps=6):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); st = call(); ts.append(time.perf_counter() - t0)
+        assert st == 0, st
+    ts = sorted(ts[1:])          # (the first call also sizes the context's staging buffers and starts its threads)
+    return ts[0], ts[len(ts) // 2]
+try:
+    quota = open('/sys/fs/cgroup/cpu.max').read().split()
+    print('CPU bandwidth of this control group (cpu.max):', ' '.join(quota), '=> ' + ('no limit' if quota[0] == 'max' else f'{int(quota[0]) / int(quota[1]):.0f} CPUs') + f'; {os.cpu_count()} hardware threads')
+except OSError:
+    pass
 W, H = 1920, 1080
 yy, xx = np.mgrid[0:H, 0:W]
 rng = np.random.default_rng(5)
@@ -29,22 +41,16 @@ ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in batch]); sizes = (C.c_size_t * 
 out_holder = torch.zeros((n, W * H * 3), dtype=torch.uint8, pin_memory=args.pinned); out = out_holder.numpy()
 mb = sum(f.size for f in batch) / 1e6
 print(f"{n} files of {W}x{H}, {mb/n*1e3:.0f} KB each" + (", the caller's pixel buffers page-locked" if args.pinned else ""))
+def line(what, t, best, med, count, with_mb=True):
+    print(f"  {what}{t:3d} host threads: best {best*1e3:7.1f} ms = {count/best:8.0f} images/s, median {med*1e3:7.1f} ms = {count/med:8.0f} images/s ({count*W*H/med/1e6:7.0f} Mpx/s" + (f", {mb/med:6.0f} MB/s of JPEG)" if with_mb else ")"))
 for t in args.threads:
-    for rep in range(2):
-        t0 = time.perf_counter()
-        st = lib.jpeg_amd_decompress_batch(ctx.handle, ptrs, sizes, n, t, 0, J.RGB.code, out.ctypes.data, 0, None)
-        dt = time.perf_counter() - t0
-        assert st == 0, st
-    print(f"  {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s  {mb/dt:8.0f} MB/s of JPEG")
+    best, med = timed(lambda: lib.jpeg_amd_decompress_batch(ctx.handle, ptrs, sizes, n, t, 0, J.RGB.code, out.ctypes.data, 0, None))
+    line("", t, best, med, n)
 # the same with the pixels left on the device (sparse coefficients up, nothing down)
 d_out = torch.zeros((n, W * H * 3), dtype=torch.uint8, device=ctx.torch_device)
 for t in args.threads:
-    for rep in range(2):
-        t0 = time.perf_counter()
-        st = lib.jpeg_amd_decompress_batch_device(ctx.handle, ptrs, sizes, n, t, 0, J.RGB.code, d_out.data_ptr(), 0, None)
-        dt = time.perf_counter() - t0
-        assert st == 0, st
-    print(f"  to device memory {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s  {mb/dt:8.0f} MB/s of JPEG")
+    best, med = timed(lambda: lib.jpeg_amd_decompress_batch_device(ctx.handle, ptrs, sizes, n, t, 0, J.RGB.code, d_out.data_ptr(), 0, None))
+    line("to device memory ", t, best, med, n)
 assert (d_out.cpu().numpy() == out).all()
 # host entropy decode alone, one thread
 info = _lib.FrameInfo(); f = batch[0]
@@ -69,19 +75,11 @@ sarr = _scan_array([[(0, 0, 0)], [(1, 1, 1), (2, 1, 1)]]); marr, nmeta, _k = _me
 cap = 1 << 20
 jout = np.zeros((n, cap), np.uint8); jsizes = (C.c_size_t * n)()
 for t in args.threads:
-    for rep in range(2):
-        t0 = time.perf_counter()
-        st = lib.jpeg_amd_compress_batch(ctx.handle, C.byref(info), px.ctypes.data, 0, n, J.RGB.code, qkey, tables.ctypes.data, tk, 2,
-                                         sarr, 2, marr, nmeta, t, jout.ctypes.data, cap, jsizes)
-        dt = time.perf_counter() - t0
-        assert st == 0, st
-    print(f"  compress {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s")
+    best, med = timed(lambda: lib.jpeg_amd_compress_batch(ctx.handle, C.byref(info), px.ctypes.data, 0, n, J.RGB.code, qkey, tables.ctypes.data, tk, 2,
+                                                          sarr, 2, marr, nmeta, t, jout.ctypes.data, cap, jsizes))
+    line("compress ", t, best, med, n, False)
 d_px = torch.from_numpy(px).to(ctx.torch_device)
 for t in args.threads:
-    for rep in range(2):
-        t0 = time.perf_counter()
-        st = lib.jpeg_amd_compress_batch_device(ctx.handle, C.byref(info), d_px.data_ptr(), 0, n, J.RGB.code, qkey, tables.ctypes.data, tk, 2,
-                                                sarr, 2, marr, nmeta, t, jout.ctypes.data, cap, jsizes)
-        dt = time.perf_counter() - t0
-        assert st == 0, st
-    print(f"  compress from device memory {t:3d} host threads: {dt*1e3:8.1f} ms  {n/dt:9.0f} images/s  {n*W*H/dt/1e6:9.0f} Mpx/s")
+    best, med = timed(lambda: lib.jpeg_amd_compress_batch_device(ctx.handle, C.byref(info), d_px.data_ptr(), 0, n, J.RGB.code, qkey, tables.ctypes.data, tk, 2,
+                                                                 sarr, 2, marr, nmeta, t, jout.ctypes.data, cap, jsizes))
+    line("compress from device memory ", t, best, med, n, False)

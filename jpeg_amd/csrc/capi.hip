@@ -1259,7 +1259,6 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
         return JPEG_AMD_OK;
     };
     struct DrainGuard { decltype(end_drain) &f; ~DrainGuard() { (void)f(); } } drain_guard{end_drain};   // joined on every way out
-    std::vector<size_t> used_of[2] = {std::vector<size_t>((size_t)chunk, 0), std::vector<size_t>((size_t)chunk, 0)};   // per slot: entries of image i (sparse images)
     std::vector<int> status_all((size_t)n_images, JPEG_AMD_OK);
     // The entropy decoding: ONE queue of files for the whole call.  A host thread takes the next file, waits (rarely) until the
     // pinned slot of the file's chunk is free, and decodes it there; this thread submits a chunk to the device as soon as its
@@ -1293,7 +1292,6 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
         uint16_t(*quanta)[64] = reinterpret_cast<uint16_t(*)[64]>(host + quanta_off + (size_t)i * kQSlotElems * 2);
         jpeg_amd_frame_info f{};
         skip[i] = 1;
-        used_of[slot][(size_t)i] = 0;
         if (!h_jpeg[file]) return JPEG_AMD_EINVAL;
         auto same_geometry = [&]() {                         // one geometry per batch: the buffers are sized for image 0
             bool same = f.width == fi.width && f.height == fi.height && f.precision == 8 && f.ncomponents == nc;
@@ -1316,7 +1314,7 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
                 const size_t at = packed_end[slot].fetch_add(blocks + n);
                 std::memcpy(reinterpret_cast<uint32_t *>(host + sparse_off) + at, record.data(), (blocks + n) * 4);
                 reinterpret_cast<uint64_t *>(host + where_off)[i] = at;
-                skip[i] = 0; used_of[slot][(size_t)i] = n;
+                skip[i] = 0;
                 sparse_done = true;
             } else if (ss != JPEG_AMD_ENOSUP) {
                 // (EINVAL may be "more blocks than image 0": the same verdict either way)

@@ -335,26 +335,6 @@ WorkerPool &pool_with(std::unique_ptr<WorkerPool> &pool, int threads)
     return *pool;
 }
 
-// fn(i) for i in [0, m) on up to `nthreads` threads; the calling thread takes a share, and the share of a worker that
-// cannot be started as well (fn does not throw)
-template <class F>
-void run_parallel(int nthreads, int m, F &&fn)
-{
-    const int t_n = std::max(1, std::min(nthreads, m));
-    std::vector<std::thread> pool;
-    int started = 1;
-    try {
-        pool.reserve((size_t)t_n);
-        for (int t = 1; t < t_n; ++t) { pool.emplace_back([&fn, t, m, t_n] { for (int i = t; i < m; i += t_n) fn(i); }); ++started; }
-    } catch (...) {
-    }
-    for (int t = started; t < t_n; ++t)
-        for (int i = t; i < m; i += t_n) fn(i);
-    for (int i = 0; i < m; i += t_n) fn(i);
-    for (std::thread &th : pool) th.join();
-}
-
-
 }  // namespace
 
 extern "C" {

@@ -217,7 +217,7 @@ def cpu_baseline(J, quanta_np, seconds, device_case=None, encode_case=None):
     reps = max(1, min(32, int(round(seconds / t1))))         # about `seconds` of single-core work
     if reps > 1:
         t1 = sum(run(planes, size, 1) for _ in range(reps)) / reps
-    ncores = os.cpu_count() or 1
+    ncores = host_cpus()
     threads = min(ncores, 64)
     run(planes, size, threads)
     tn = min(run(planes, size, threads) for _ in range(3))
@@ -227,7 +227,7 @@ def cpu_baseline(J, quanta_np, seconds, device_case=None, encode_case=None):
     except Exception:
         model = "unknown"
     parity = {}
-    nthr = min(64, os.cpu_count() or 1)
+    nthr = min(64, host_cpus())
     if device_case is not None:
         planes_d, pixels_d, size_d = device_case
         _, rect = O.decode(planes_d, [quanta_np[0], quanta_np[1], quanta_np[1]], [(2, 2), (1, 1), (1, 1)], size_d, threads=nthr)
@@ -383,7 +383,7 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
         barrier()
 
     workload = args.workload if args.workload != "auto" else "c3"   # ONE workload under `value` at every N
-    check_threads = max(1, min(64, (os.cpu_count() or 1) // world))
+    check_threads = max(1, min(64, host_cpus() // world))
     if make_workload is None:
         def make_workload(name, width, height, n_images, ring, quanta, seed):
             return DecodeWorkload(J, ctx, width, height, n_images, ring, quanta, seed)

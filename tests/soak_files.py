@@ -20,8 +20,8 @@ for it in range(N):
     factors = LAYOUTS[name]
     nc = len(factors)
     w, h = int(rng.integers(1, 500)), int(rng.integers(1, 300))
-    n = int(rng.choice([1, 2, 5, 33, 70]))
-    threads = int(rng.choice([1, 3, 8]))
+    n = int(rng.choice([1, 2, 5, 33, 70, 150]))
+    threads = int(rng.choice([1, 2, 3, 8, 16, 40]))
     ri = int(rng.choice([0, 0, 1, 7, 64]))
     level = float(rng.choice([0.25, 1.0, 4.0]))
     dense = rng.integers(6) == 0                      # now and then pictures too dense for the sparse arenas

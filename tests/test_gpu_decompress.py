@@ -265,3 +265,35 @@ def test_decompress_batch_device_leaves_the_pixels_on_the_device(ctx):
         for i in range(n):
             assert G.sha(got[i * stride:i * stride + w * h * 3]) == G.entry(names[i % len(names)])["gold"]["rgb_sha256"], (i, threads)
             assert not got[i * stride + w * h * 3:(i + 1) * stride].any()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("device_out", [False, True])
+def test_a_bad_file_in_the_middle_of_a_batch_fails_the_call_and_leaves_the_context_usable(ctx, device_out):
+    """70 files, the 41st cut off inside its frame header: the call reports the error (and returns: the threads waiting for
+    later chunks are told to stop), and the next call on the same context -- same staging, same threads -- is right."""
+    import torch
+    import jpeg_amd as J
+    lib = _lib.lib()
+    name = "color-sequential-1.jpg"
+    good = np.fromfile(G.path(G.entry(name)["file"]), np.uint8)
+    bad = good[:40].copy()
+    w, h = G.entry(name)["width"], G.entry(name)["height"]
+    n = 70
+    def call(files, threads):
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in files])
+        sizes = (C.c_size_t * n)(*[f.size for f in files])
+        if device_out:
+            out = torch.zeros(n * w * h * 3, dtype=torch.uint8, device=ctx.torch_device)
+            st = lib.jpeg_amd_decompress_batch_device(ctx.handle, ptrs, sizes, n, threads, 0, J.RGB.code, out.data_ptr(), 0, None)
+            return st, out.cpu().numpy()
+        out = np.zeros(n * w * h * 3, np.uint8)
+        st = lib.jpeg_amd_decompress_batch(ctx.handle, ptrs, sizes, n, threads, 0, J.RGB.code, out.ctypes.data, 0, None)
+        return st, out
+    for threads in (1, 6):
+        st, _ = call([bad if i == 40 else good for i in range(n)], threads)
+        assert st == _lib.EINVAL
+        st, out = call([good] * n, threads)
+        assert st == 0
+        for i in (0, 39, 40, 69):
+            assert G.sha(out[i * w * h * 3:(i + 1) * w * h * 3]) == G.entry(name)["gold"]["rgb_sha256"]

@@ -366,20 +366,22 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     // ---- phase A2: Rectangular.decomposed() from there into the plane tiles.  The sum of the 1, 2 or 4 samples under a plane
     //      sample is below 2^24, so Float(sum) is exact, its quotient by 1, 2 or 4 is exact, and the truncation of that
     //      quotient (encode.swift:404, :422) is the sum shifted right ----
-    for (int i = t; i < first[COUNT]; i += kGThreads) {
-        int p = 0;
+    // (plane by plane: which plane a sample belongs to, and with it the shape of its box, is then the same for the whole wave --
+    // per-lane selects are v_cndmask_b32, the one instruction that issues ten times slower than the rest)
 #pragma unroll
-        for (int q = 1; q < COUNT; ++q) p += i >= first[q];
-        int f0 = first[0], w = tw[0], rx = a.pl[0].rx, ry = a.pl[0].ry;
-#pragma unroll
-        for (int q = 1; q < COUNT; ++q)
-            if (p == q) { f0 = first[q]; w = tw[q]; rx = a.pl[q].rx; ry = a.pl[q].ry; }
-        const int local = i - f0, ly = local / w, lx = local - ly * w;
-        const uint16_t *box = raw + (ly * ry) * RP + (lx * rx) * COUNT + p;
-        uint32_t sum = box[0];
-        if (rx == 2) sum += box[COUNT];
-        if (ry == 2) { sum += box[RP]; if (rx == 2) sum += box[RP + COUNT]; }
-        tile[i] = (uint16_t)(sum >> ((rx == 2) + (ry == 2)));
+    for (int p = 0; p < COUNT; ++p) {
+        const int rx = a.pl[p].rx, ry = a.pl[p].ry;
+        const int shift = rx == 2 ? 6 : 7;                    // the plane tile is 128 / rx samples wide: a power of two
+        uint16_t *dst = tile + first[p];
+        const int nsamples = first[p + 1] - first[p];
+        for (int local = t; local < nsamples; local += kGThreads) {
+            const int ly = local >> shift, lx = local & ((1 << shift) - 1);
+            const uint16_t *box = raw + (ly * ry) * RP + (lx * rx) * COUNT + p;
+            uint32_t sum = box[0];
+            if (rx == 2) sum += box[COUNT];
+            if (ry == 2) { sum += box[RP]; if (rx == 2) sum += box[RP + COUNT]; }
+            dst[local] = (uint16_t)(sum >> ((rx == 2) + (ry == 2)));
+        }
     }
     __syncthreads();
 
@@ -442,22 +444,21 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     // ---- phase C: blocks out through LDS (the raw tile is no longer needed); chunk c of block t sits at slot c ^ (t & 7) ----
     const uint4 *stage = reinterpret_cast<const uint4 *>(raw);
     __syncthreads();
-    for (int j = t; j < 8 * fb[COUNT]; j += kGThreads) {
-        const int b = j >> 3, c = j & 7;
-        int q = 0;
+    // (plane by plane, like phase A2: no per-lane selects)
 #pragma unroll
-        for (int r = 1; r < COUNT; ++r) q += b >= fb[r];
-        int b0 = fb[0], wpx = tw[0];
-        int16_t *coef = a.pl[0].coef;
-        size_t stride = a.pl[0].stride;
-        int ux = a.pl[0].ux, uy = a.pl[0].uy, rx = a.pl[0].rx, ry = a.pl[0].ry;
-#pragma unroll
-        for (int r = 1; r < COUNT; ++r)
-            if (q == r) { b0 = fb[r]; wpx = tw[r]; coef = a.pl[r].coef; stride = a.pl[r].stride; ux = a.pl[r].ux; uy = a.pl[r].uy; rx = a.pl[r].rx; ry = a.pl[r].ry; }
-        const int nbx = wpx / 8, local = b - b0, lby = local / nbx, lbx = local - lby * nbx;
-        const int bx = x0 / (8 * rx) + lbx, by = y0 / (8 * ry) + lby;
-        if (bx < ux && by < uy)
-            *reinterpret_cast<uint4 *>(coef + img * stride + (size_t)64 * ((size_t)by * ux + bx) + 8 * c) = stage[8 * b + (c ^ (b & 7))];
+    for (int q = 0; q < COUNT; ++q) {
+        const int nbx = tw[q] / 8, rx = a.pl[q].rx, ry = a.pl[q].ry, ux = a.pl[q].ux, uy = a.pl[q].uy;
+        const int shift = rx == 2 ? 3 : 4;                    // 16 / rx blocks per tile row
+        int16_t *coef = a.pl[q].coef + img * a.pl[q].stride;
+        const int bx0 = x0 / (8 * rx), by0 = y0 / (8 * ry);
+        (void)nbx;
+        for (int j = t; j < 8 * (fb[q + 1] - fb[q]); j += kGThreads) {
+            const int local = j >> 3, c = j & 7, b = fb[q] + local;
+            const int lby = local >> shift, lbx = local & ((1 << shift) - 1);
+            const int bx = bx0 + lbx, by = by0 + lby;
+            if (bx < ux && by < uy)
+                *reinterpret_cast<uint4 *>(coef + (size_t)64 * ((size_t)by * ux + bx) + 8 * c) = stage[8 * b + (c ^ (b & 7))];
+        }
     }
 }
 

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     __shared__ __attribute__((aligned(16))) uint16_t raw[GEW * GEH * COUNT];    // the tile of Rectangular; later the blocks on their way out
     extern __shared__ __attribute__((aligned(16))) uint16_t tile[];                // plane tiles: as many samples as the layout's planes have under a tile
     __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                                // modulated tables (natural order, scale 8)
+    __shared__ int4 par[JPEG_AMD_MAX_PLANES][2];                                 // per plane: first block, first sample, tile width, units, ratios
 
     const int t = threadIdx.x, img = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
@@ -338,6 +339,10 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
         tw[p] = GEW / a.pl[p].rx; th[p] = GEH / a.pl[p].ry;
         first[p + 1] = first[p] + tw[p] * th[p];
         fb[p + 1] = fb[p] + (tw[p] / 8) * (th[p] / 8);
+    }
+    if (t < COUNT) {
+        par[t][0] = make_int4(fb[t], first[t], tw[t], a.pl[t].ux);
+        par[t][1] = make_int4(a.pl[t].uy, a.pl[t].rx, a.pl[t].ry, 0);
     }
     // ---- phase A1: the tile of Rectangular as it lies in memory -> LDS, 16 bytes per work-item and step; a sample beyond the
     //      image is the nearest one inside (encode.swift:415-417: the box clamps its indices), fetched one at a time ----
@@ -393,15 +398,11 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     if (blk < fb[COUNT]) {
 #pragma unroll
         for (int q = 1; q < COUNT; ++q) p += blk >= fb[q];
-        int b0 = fb[0], f0 = first[0], wpx = tw[0];
-#pragma unroll
-        for (int q = 1; q < COUNT; ++q)
-            if (p == q) { b0 = fb[q]; f0 = first[q]; wpx = tw[q]; }
-        const int nbx = wpx / 8, local = blk - b0, lby = local / nbx, lbx = local - lby * nbx;
-        int ux = a.pl[0].ux, uy = a.pl[0].uy, rx = a.pl[0].rx, ry = a.pl[0].ry;
-#pragma unroll
-        for (int q = 1; q < COUNT; ++q)
-            if (p == q) { ux = a.pl[q].ux; uy = a.pl[q].uy; rx = a.pl[q].rx; ry = a.pl[q].ry; }
+        // the plane's parameters from a small LDS table indexed by p (a chain of per-lane selects would be 7 (COUNT - 1) v_cndmask_b32)
+        const int4 pa = par[p][0], pb = par[p][1];
+        const int b0 = pa.x, f0 = pa.y, wpx = pa.z, ux = pa.w, uy = pb.x, rx = pb.y, ry = pb.z;
+        const int shift = rx == 2 ? 3 : 4;                    // 16 / rx blocks per tile row
+        const int local = blk - b0, lby = local >> shift, lbx = local & ((1 << shift) - 1);
         gbx = x0 / (8 * rx) + lbx; gby = y0 / (8 * ry) + lby;
         have = gbx < ux && gby < uy;
         if (have) {

@@ -40,6 +40,13 @@ PY
 for c in c3 c5 c2 c4; do cp $O/$c/kernel_stats.csv profiles/${tag}_${c}_kernel_stats.csv; cp $O/$c/pmc_fetch_size.csv profiles/${tag}_${c}_pmc_fetch_size.csv; cp $O/$c/pmc_write_size.csv profiles/${tag}_${c}_pmc_write_size.csv; done
 python3 bench.py > $O/bench.json 2> $O/bench.log
 cp $O/bench.json profiles/${tag}_bench.json
+python3 - <<PY
+# the record has to agree with itself: the profiler's mean duration of the headline kernel against the wall time per step of the bench line
+import csv, json
+b = json.load(open("$O/bench.json"))
+k = next(float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open("$O/c3/kernel_stats.csv")) if "k_quad420" in r["Name"])
+print(f"C3: rocprofv3 mean {k * 1e3:.1f} us, bench.py {b['ms_per_step'] * 1e3:.1f} us per step:", "agree" if abs(k / b["ms_per_step"] - 1) < 0.05 else "DISAGREE (a noisy box: run the record again)")
+PY
 cat $O/traffic.json | head -80
 cut -c1-1500 $O/bench.json
 # profiles/ is not copied back from the GPU box, gpurun_out/ is: leave the files to commit there

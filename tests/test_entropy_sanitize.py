@@ -20,3 +20,14 @@ def test_entropy_coder_is_clean_under_asan_and_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, *files], capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-800:], r.stderr[-2000:])
+
+
+def test_worker_pool_is_clean_under_tsan(tmp_path):
+    """The host thread pool of the batch file paths (csrc/worker_pool.hpp) under ThreadSanitizer: regions of every size and
+    thread limit on pools of 1, 2, 5 and 16 threads -- every item exactly once, never more threads than the region was given,
+    begin() / finish() apart -- and the directing-thread queue pattern of jpeg_amd_decompress_batch to its end."""
+    exe = str(tmp_path / "worker_pool_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", os.path.join(ROOT, "jpeg_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "worker_pool_test.cpp"), "-o", exe, "-lpthread"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-800:], r.stderr[-2000:])

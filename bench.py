@@ -248,7 +248,7 @@ def cpu_baseline(J, quanta_np, seconds, device_case=None, encode_case=None):
     }
 
 
-DECODE_SOURCES = ("kernels_quad.hip", "kernels_fused.hip", "fused_common.hpp", "dct.hpp", "upsample.hpp", "kernels.hpp", "capi.hip")
+DECODE_SOURCES = ("kernels_quad.hip", "kernels_fused.hip", "fused_common.hpp", "dct.hpp", "upsample.hpp", "kernels.hpp", "capi.hip")   # (tools/make_traffic.py hashes the same list)
 
 
 def kernel_source_sha16():

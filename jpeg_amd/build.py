@@ -24,13 +24,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 
 
 # kernels that must not touch scratch memory: source -> mangled-name fragment.  The strip walks count their own VM operations
-# (a compiler-placed spill would break the count); for the encode and generic kernels a spill is a performance bug -- a reload
-# waits with vmcnt(0) for every store in flight -- that has crept in before (round 4: the byte-tail encode variants).
-NO_SCRATCH = {"kernels_quad.hip": "k_quad420", "kernels_fused.hip": "k_luma_fused", "kernels_encode.hip": "k_encode_fused",
-              "kernels_generic.hip": "k_generic_fused"}
+# (a compiler-placed spill would break the count): for them a spill is a build ERROR.  For the encode and generic kernels a spill is
+# a performance bug -- a reload waits with vmcnt(0) for every store in flight -- that has crept in before (round 4: the byte-tail
+# encode variants): it is reported, and an error only under JPEG_AMD_STRICT_SPILL=1 (a register-allocation change in a ROCm update
+# must not leave a user without a library).
+NO_SCRATCH = {"kernels_quad.hip": "k_quad420", "kernels_fused.hip": "k_luma_fused"}
+WARN_SCRATCH = {"kernels_encode.hip": "k_encode_fused", "kernels_generic.hip": "k_generic_fused"}
 
 
-def check_no_scratch(src: str, remarks: str, fragment: str) -> None:
+def check_no_scratch(src: str, remarks: str, fragment: str, strict: bool = True) -> None:
     """Parse hipcc's kernel-resource-usage remarks: every kernel whose name contains `fragment` must report
     ScratchSize 0 and no spilled registers."""
     cur, seen, bad = None, 0, []
@@ -44,8 +46,10 @@ def check_no_scratch(src: str, remarks: str, fragment: str) -> None:
                     bad.append(f"{cur}: {key} {line.split(key)[1].split('[-R')[0].strip()}")
     if seen == 0:
         raise RuntimeError(f"{src}: no resource remarks for {fragment} (the spill gate cannot see the kernels)")
-    if bad:
+    if bad and strict:
         raise RuntimeError(f"{src}: kernels of the spill gate (NO_SCRATCH) must not spill:\n  " + "\n  ".join(bad))
+    if bad:
+        sys.stderr.write(f"jpeg_amd.build: warning: {src}: spilling kernels (a performance bug, not an error):\n  " + "\n  ".join(bad) + "\n")
 
 
 def hipcc() -> str:
@@ -65,13 +69,16 @@ def _stale() -> bool:
 
 
 def sync_swift_header() -> None:
-    """swift/Sources/CJPEGAMD/jpeg_amd.h is a generated copy of include/jpeg_amd.h (the module map needs the header inside
-    the C target's directory); tests/test_abi_cpu.py checks that the two are identical.  Only the explicit build
-    (`python -m jpeg_amd.build`) writes it -- never a library load, which may run on a read-only checkout or as several
-    ranks at once -- and it writes atomically."""
+    """swift/Sources/CJPEGAMD/jpeg_amd.h must be include/jpeg_amd.h (the module map needs the header inside the C target's
+    directory); tests/test_abi_cpu.py checks that the two are identical.  In this repository it is a tracked SYMLINK to the
+    header and is left alone; where a checkout has a regular file there (no symlink support), the explicit build
+    (`python -m jpeg_amd.build`) refreshes the copy -- never a library load, which may run on a read-only checkout or as
+    several ranks at once -- and it writes atomically."""
     src = os.path.join(INCLUDE, "jpeg_amd.h")
     dst = os.path.join(os.path.dirname(HERE), "swift", "Sources", "CJPEGAMD", "jpeg_amd.h")
     if not os.path.isdir(os.path.dirname(dst)):
+        return
+    if os.path.islink(dst) and os.path.realpath(dst) == os.path.realpath(src):
         return
     data = open(src, "rb").read()
     try:
@@ -95,7 +102,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         cmd = [cc, *FLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        if src in NO_SCRATCH:
+        if src in NO_SCRATCH or src in WARN_SCRATCH:
             # these kernels count their own VM operations (`s_waitcnt vmcnt(16)` behind the coefficient DMA): a compiler-
             # generated scratch store or reload in that window would break the count, so a spill is a build error
             proc = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
@@ -104,7 +111,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 sys.stderr.write("\n".join(remarks) + "\n")
             if proc.returncode != 0:
                 raise subprocess.CalledProcessError(proc.returncode, cmd)
-            check_no_scratch(src, proc.stderr, NO_SCRATCH[src])
+            if src in NO_SCRATCH:
+                check_no_scratch(src, proc.stderr, NO_SCRATCH[src])
+            else:
+                check_no_scratch(src, proc.stderr, WARN_SCRATCH[src], strict=os.environ.get("JPEG_AMD_STRICT_SPILL") == "1")
         else:
             subprocess.check_call(cmd)
         objs.append(obj)

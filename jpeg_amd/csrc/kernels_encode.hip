@@ -20,7 +20,9 @@
 //   - Float(sum) / Float(n) truncated, n in {1, 2, 4}, is floor(sum * (1/n)) exactly.
 //
 // Development switches (tools/build_exp.sh, never in the product build): JA_X_ENC_NOSTORE,
-// JA_X_ENC_L2LOAD -- the kernel without its stores / with every load hitting L2; JA_X_ENC_NOCHROMA -- without the two-wave
+// JA_X_ENC_L2LOAD -- the kernel without its stores / with every load hitting L2; JA_X_ENC_NOCOMPUTE -- its memory traffic with next to no
+// arithmetic (round 6, profiles/r06_ablate_encode.txt: memory alone and arithmetic alone need the same 71 us at 8192 x 8192, the kernel 93);
+// JA_X_ENC_NOCHROMA -- without the two-wave
 // chroma tail of a tile (round 4: 23.6 -> 19.3 us at 4096 x 4096, 86.1 -> 68.7 at 8192 x 8192: the tail's share of the
 // tile's instructions, 18 %, is its share of the time -- the kernel is bound by the instructions it issues in all, not by
 // the longest wave); JA_X_ENC_TY, JA_X_ENC_PERHALF_WAVES.
@@ -90,20 +92,32 @@ constexpr ColumnOfZigzag kColumnOfZigzag{};
 template <int M>
 constexpr int pair_ready_after() { return kColumnOfZigzag.k[2 * M] > kColumnOfZigzag.k[2 * M + 1] ? kColumnOfZigzag.k[2 * M] : kColumnOfZigzag.k[2 * M + 1]; }
 
+// copysign(pred(1/2), y) as ONE full-rate instruction: v_bitop3_b32 with the truth table "S0 ? S1 : S2" per bit (0xca) selects the magnitude's
+// bits under the mask 0x7fffffff and y's sign bit elsewhere.  (The compiler's v_bfi_b32 for __builtin_copysignf issues at half the rate:
+// tools/probe_rates3.hip, profiles/r06_probe_rates3.txt; bit-identical by construction, tools/probe_typed.hip T4.)
+__device__ __forceinline__ float half_toward(float y)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(0x7fffffffu, __builtin_bit_cast(uint32_t, 0.49999997f), __builtin_bit_cast(uint32_t, y), 0xca));
+}
+
+// The pair of zigzag slots (2m, 2m + 1), truncated and packed by TWO conversions: v_cvt_i32_f32 writes the first integer, and the
+// second conversion's SDWA destination select puts its low 16 bits into the upper half of the same register (dst_unused:
+// UNUSED_PRESERVE) -- no v_cvt_pk_i16_i32 behind them (tools/probe_typed.hip T3: 2^20 random pairs).  |coefficient| < 2^15, so the
+// low halves ARE the int16 values.  (Round 6: 5 % fewer issue cycles by the cost table and no measurable change of the kernel's
+// time -- profiles/r06_ab_encode_quantiser.txt: the kernel is not bound by VALU issue alone.)
 template <int M>
-__device__ __forceinline__ void pack_pair_if_ready(const int (&ci)[64], uint32_t (&w)[32], int k)
+__device__ __forceinline__ void pack_pair_if_ready(const float (&zf)[64], uint32_t (&w)[32], int k)
 {
     if (pair_ready_after<M>() == k) {   // k is a constant after unrolling
-        typedef short short2_t __attribute__((ext_vector_type(2)));
-        const short2_t pk = __builtin_amdgcn_cvt_pk_i16(ci[2 * M], ci[2 * M + 1]);   // |coefficient| < 2^15: never saturates
-        w[M] = __builtin_bit_cast(uint32_t, pk);
-        asm volatile("" : "+v"(w[M]));
+        asm volatile("v_cvt_i32_f32_e32 %0, %1\n\t"
+                     "v_cvt_i32_f32_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD"
+                     : "=&v"(w[M]) : "v"(zf[2 * M]), "v"(zf[2 * M + 1]));
     }
 }
 template <int... M>
-__device__ __forceinline__ void pack_ready_pairs(const int (&ci)[64], uint32_t (&w)[32], int k, std::integer_sequence<int, M...>)
+__device__ __forceinline__ void pack_ready_pairs(const float (&zf)[64], uint32_t (&w)[32], int k, std::integer_sequence<int, M...>)
 {
-    (pack_pair_if_ready<M>(ci, w, k), ...);
+    (pack_pair_if_ready<M>(zf, w, k), ...);
 }
 
 // FDCT + quantise + zigzag scatter of one block held as 64 floats g[8y + x]; q / rq = modulated
@@ -133,9 +147,9 @@ __device__ __forceinline__ void fdct_quantise(const float (&g)[64], const float 
     // arithmetic of all eight columns around the table reads and needs > 200 VGPRs (spills).
 #pragma unroll
     for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(f[i]));
-    // w: 64 quantised coefficients, zigzag order, packed in pairs: a pair is packed by ONE v_cvt_pk_i16_i32 as soon as
-    // the later of its two columns is done (zigzag neighbours lie at most one column apart, so few integers wait)
-    int ci[64];   // by zigzag index
+    // w: 64 quantised coefficients, zigzag order, packed in pairs: a pair is converted and packed as soon as the later of its two
+    // columns is done (zigzag neighbours lie at most one column apart, so few values wait)
+    float zf[64];   // by zigzag index: y1 + copysign(pred(1/2), y1), whose truncation is the rounded coefficient
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         __builtin_amdgcn_sched_barrier(0);
@@ -149,9 +163,9 @@ __device__ __forceinline__ void fdct_quantise(const float (&g)[64], const float 
             const float y0 = res[h] * rr;
             const float e  = __builtin_fmaf(-y0, qq, res[h]);
             const float y1 = __builtin_fmaf(e, rr, y0);
-            ci[zigzag_of(k, h)] = (int)(y1 + __builtin_copysignf(0.49999997f, y1));  // the cast truncates; scatter (encode.swift:236-239)
+            zf[zigzag_of(k, h)] = y1 + half_toward(y1);  // the conversion truncates; scatter (encode.swift:236-239)
         }
-        pack_ready_pairs(ci, w, k, std::make_integer_sequence<int, 32>{});
+        pack_ready_pairs(zf, w, k, std::make_integer_sequence<int, 32>{});
     }
 }
 
@@ -319,7 +333,12 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? ((CHROMA && SX == 1 && SY == 1
                 g[8 * y + 6] = ubyte<2>(d1); g[8 * y + 7] = ubyte<3>(d1);
             }
             uint32_t w[32];
+#ifdef JA_X_ENC_NOCOMPUTE   // experiment (wrong coefficients): the kernel's memory traffic with next to no arithmetic
+#pragma unroll
+            for (int i = 0; i < 32; ++i) w[i] = __builtin_bit_cast(uint32_t, g[2 * i]) ^ __builtin_bit_cast(uint32_t, g[2 * i + 1]);
+#else
             fdct_quantise(g, sq[1 + pl], sr[1 + pl], w);
+#endif
             // 2 * CBX * CBY and CBX * CBY are multiples of 64: the loop is wave-uniform and a wave
             // never straddles the two planes
             const int plu = __builtin_amdgcn_readfirstlane(pl);
@@ -485,7 +504,16 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? ((CHROMA && SX == 1 && SY == 1
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) c[ch][x] = x <= xlast ? c[ch][x] : c[ch][x - 1];
             }
+#ifdef JA_X_ENC_NOCOMPUTE
+#pragma unroll
+            for (int x = 0; x < 8; ++x) yv[8 * y + x] = c[0][x] + c[1][x] + c[2][x];
+            if (y == 7 && CHROMA && !INTHREAD) {
+                uint32_t *row = sc + (lby * 4 * CPITCH + lbx) % (2 * CH * CPITCH);
+                row[0] = pix[0][0];
+            }
+#else
             emit_row(y, c[0], c[1], c[2]);
+#endif
 #pragma unroll
             for (int x = 0; x < 8; ++x) asm volatile("" : "+v"(yv[8 * y + x]));
         }
@@ -494,7 +522,12 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? ((CHROMA && SX == 1 && SY == 1
         __builtin_amdgcn_sched_barrier(0);
         {
             uint32_t w[32];
+#ifdef JA_X_ENC_NOCOMPUTE
+#pragma unroll
+            for (int i = 0; i < 32; ++i) w[i] = __builtin_bit_cast(uint32_t, yv[2 * i]) ^ __builtin_bit_cast(uint32_t, yv[2 * i + 1]);
+#else
             fdct_quantise(yv, sq[0], sr[0], w);
+#endif
             const uint32_t off = (bx < a.ux[0] && by < a.uy[0]) ? (uint32_t)(by * a.ux[0] + bx) : ~0u;
             store_blocks(w, stage, lane, a.coef[0] + img * a.coef_stride[0], off);
         }

@@ -7,8 +7,8 @@
 // files (examples/encode-basic/*.jpg, pinned by SHA-256 in tests/golden/MANIFEST.json), so the
 // places where the reference differs from a textbook encoder are mirrored and cited:
 //   - optimal Huffman lengths from a binary min-heap with strict `<` sift tests, a zero-weight
-//     dummy leaf for the all-ones code, 16-bit length limiting by promoting node pairs and
-//     splitting leaves from level 15 upwards                      encode.swift:597-760, common.swift:127-300
+//     dummy leaf for the all-ones code, and a 16-bit length limit that grows codes at the deepest
+//     level that still has a leaf (stated here through the Kraft sum)   encode.swift:597-760, common.swift:127-300
 //   - symbols ordered by decreasing frequency, ties in ascending symbol value (stable sort)  :716-731
 //   - a run of 16 zeros is emitted as ZRL as soon as it is complete, also when only zeros
 //     follow (so trailing zeros cost ZRLs before the EOB, and a trailing run that is a
@@ -88,98 +88,109 @@ struct MinHeap {
     }
 };
 
-// leaves per depth 1.. of the merge tree -> at most 16 levels, all-ones code removed
-std::vector<int> limit_levels(std::vector<int> levels, int height)
+// Code lengths limited to 16 bits, on the histogram of leaf depths alone (leaves[d]: leaves at depth d of the merge tree,
+// the zero-weight dummy among the deepest).  Stated through the Kraft sum: a full binary tree satisfies
+//     sum over d of leaves[d] * 2^-d = 1,
+// so what hangs BELOW depth 16 is known without looking at it -- the nodes at depth 16 that are not leaves number
+//     inner16 = 2^16 - sum over d <= 16 of leaves[d] * 2^(16 - d),
+// each of them the root of a subtree that becomes ONE leaf slot at depth 16 when the tree is cut there.  The `deeper` leaves of
+// those subtrees fill the inner16 new slots; the rest (deeper - inner16) has no place yet.  A place is made by turning a leaf of
+// depth d < 16 into an inner node with two children at depth d + 1 (one for the old leaf, one for a homeless one) -- always at
+// the deepest depth that still has a leaf, the cheapest place for a code to grow by one bit.  Last, the dummy leaves the deepest
+// level: its all-ones code word is the one T.81 forbids.  (The reference reaches the same histogram by promoting sibling pairs
+// level by level and splitting leaves from level 15 upwards, encode.swift:597-660; the 32 + 4 files its writer produced, reproduced
+// byte for byte by tests/test_entropy_encode_cpu.py and tests/test_gpu_compress.py, are the proof of equivalence.)
+bool limit_to_16_bits(const std::vector<long> &leaves /* [0] unused */, int counts_out[17])
 {
-    if ((int)levels.size() <= height) {
-        levels.back() -= 1;
-        return levels;
+    const int deepest = (int)leaves.size() - 1;
+    for (int d = 0; d <= 16; ++d) counts_out[d] = d <= deepest ? (int)leaves[d] : 0;
+    if (deepest <= 16) {
+        counts_out[deepest] -= 1;
+        return true;
     }
-    int unhoused = 0;
-    for (int l = (int)levels.size() - 1; l >= height; --l) {
-        const int pairs = levels[l] >> 1;   // a full tree: even count on every level below the root
-        unhoused += pairs;
-        levels[l - 1] += pairs;
+    long occupied = 0, deeper = 0;                       // Kraft sum of depths 1 .. 16 in units of 2^-16; leaves below depth 16
+    for (int d = 1; d <= 16; ++d) occupied += leaves[d] << (16 - d);
+    for (int d = 17; d <= deepest; ++d) deeper += leaves[d];
+    const long inner16 = 65536 - occupied;
+    long homeless = deeper - inner16;
+    if (inner16 <= 0 || homeless < 0) return false;     // not the depth histogram of a full tree
+    counts_out[16] += (int)inner16;
+    while (homeless > 0) {
+        int d = 15;
+        while (d >= 1 && counts_out[d] == 0) --d;
+        if (d < 1) return false;
+        const long grown = std::min<long>(counts_out[d], homeless);
+        counts_out[d] -= (int)grown;
+        counts_out[d + 1] += (int)(2 * grown);
+        homeless -= grown;
     }
-    levels.resize(height);
-    int split = height - 2;
-    while (unhoused > 0) {
-        if (levels[split] <= 0) { --split; continue; }
-        const int resettled = std::min(levels[split], unhoused);
-        unhoused -= resettled;
-        levels[split] -= resettled;
-        levels[split + 1] += 2 * resettled;
-        if (split < height - 2) ++split;
-    }
-    levels[height - 1] -= 1;
-    return levels;
+    counts_out[16] -= 1;
+    return true;
 }
 
+// The optimal code of a symbol histogram, as the reference builds it (encode.swift:700-768): code lengths from a Huffman merge on
+// the binary min-heap above -- fed with the symbols in order of INCREASING frequency (equal frequencies: the larger symbol
+// first), heapified bottom-up, then joined by a zero-weight dummy --, limited to 16 bits, and handed out shortest first to the
+// symbols in order of DECREASING frequency (equal frequencies: the smaller symbol first).  The feeding order and the heap's
+// strict comparisons decide which of several optimal trees comes out, i.e. they are part of what "the reference's file" means.
 bool build_codebook(const long freq[256], Codebook &cb)
 {
-    struct Entry { long f; int sym; };
-    std::vector<Entry> sorted;
+    struct Weighted { long weight; int symbol; };
+    std::vector<Weighted> rising;                        // the heap's feeding order
     for (int v = 0; v < 256; ++v)
-        if (freq[v] > 0) sorted.push_back({freq[v], v});
-    if (sorted.empty()) return false;
-    std::stable_sort(sorted.begin(), sorted.end(), [](const Entry &x, const Entry &y) { return x.f > y.f; });
+        if (freq[v] > 0) rising.push_back({freq[v], v});
+    if (rising.empty()) return false;
+    std::sort(rising.begin(), rising.end(), [](const Weighted &x, const Weighted &y) {
+        return x.weight != y.weight ? x.weight < y.weight : x.symbol > y.symbol;
+    });
+    const int n_symbols = (int)rising.size();
 
-    struct Node { int left, right; };   // leaf: left < 0
-    std::vector<Node> nodes;
+    // merge tree as parent links: nodes 0 .. n_symbols - 1 the symbols (feeding order), n_symbols the dummy, then the merges
+    std::vector<int> parent(2 * (size_t)n_symbols + 2, -1);
     MinHeap heap;
-    for (auto it = sorted.rbegin(); it != sorted.rend(); ++it) {
-        nodes.push_back({-1, -1});
-        heap.a.push_back({it->f, (int)nodes.size() - 1});
-    }
+    for (int i = 0; i < n_symbols; ++i) heap.a.push_back({rising[i].weight, i});
     heap.heapify();
-    nodes.push_back({-1, -1});
-    heap.push(0, (int)nodes.size() - 1);   // the dummy that will own the all-ones code
-
-    MinHeap::Item first, second;
-    int root = -1;
-    while (heap.pop(first)) {
-        if (!heap.pop(second)) { root = first.node; break; }
-        nodes.push_back({first.node, second.node});
-        heap.push(first.key + second.key, (int)nodes.size() - 1);
+    heap.push(0, n_symbols);                             // the dummy that will own the all-ones code
+    int made = n_symbols + 1;
+    for (;;) {
+        MinHeap::Item lighter, heavier;
+        if (!heap.pop(lighter)) return false;
+        if (!heap.pop(heavier)) break;                   // `lighter` was the root
+        parent[lighter.node] = parent[heavier.node] = made;
+        heap.push(lighter.key + heavier.key, made);
+        ++made;
     }
-    // leaves per depth, breadth first; the root level is dropped
-    std::vector<int> levels;
-    std::vector<int> queue{root}, next;
-    bool is_root = true;
-    while (!queue.empty()) {
-        int leaves = 0;
-        next.clear();
-        for (int n : queue) {
-            if (nodes[n].left < 0) ++leaves;
-            else { next.push_back(nodes[n].left); next.push_back(nodes[n].right); }
-        }
-        if (!is_root) levels.push_back(leaves);
-        is_root = false;
-        queue.swap(next);
-    }
-    if (levels.empty()) return false;
-    const std::vector<int> limited = limit_levels(levels, 16);
+    // a merge is created after both of its children: one sweep from the root down gives every node its depth
+    std::vector<int> depth((size_t)made, 0);
+    for (int node = made - 2; node >= 0; --node) depth[node] = depth[parent[node]] + 1;
+    int deepest = 0;
+    for (int leaf = 0; leaf <= n_symbols; ++leaf) deepest = std::max(deepest, depth[leaf]);
+    if (deepest == 0) return false;
+    std::vector<long> leaves((size_t)deepest + 1, 0);
+    for (int leaf = 0; leaf <= n_symbols; ++leaf) leaves[depth[leaf]] += 1;
+    int per_length[17];
+    if (!limit_to_16_bits(leaves, per_length)) return false;
 
     std::memset(&cb.code, 0, sizeof cb.code);
     std::memset(&cb.length, 0, sizeof cb.length);
     std::memset(&cb.counts, 0, sizeof cb.counts);
     cb.symbols.clear();
-    unsigned counter = 0;
-    size_t base = 0;
-    for (int l = 0; l < 16; ++l) {
-        const int leaves = l < (int)limited.size() ? limited[l] : 0;
-        if (leaves < 0 || base + (size_t)leaves > sorted.size() || leaves > 255) return false;
-        cb.counts[l] = (uint8_t)leaves;
-        for (int i = 0; i < leaves; ++i, ++counter) {
-            const int sym = sorted[base + i].sym;
-            cb.code[sym] = (uint16_t)counter;
-            cb.length[sym] = (uint8_t)(l + 1);
+    // canonical code words (T.81 Annex C): lengths ascending; the most frequent symbol is the last of `rising`
+    unsigned word = 0;
+    int next = n_symbols - 1;
+    for (int bits = 1; bits <= 16; ++bits) {
+        const int here = per_length[bits];
+        if (here < 0 || here > 255 || here > next + 1) return false;
+        cb.counts[bits - 1] = (uint8_t)here;
+        for (int i = 0; i < here; ++i, --next, ++word) {
+            const int sym = rising[next].symbol;
+            cb.code[sym] = (uint16_t)word;
+            cb.length[sym] = (uint8_t)bits;
             cb.symbols.push_back((uint8_t)sym);
         }
-        base += (size_t)leaves;
-        counter <<= 1;
+        word <<= 1;
     }
-    return base == sorted.size();
+    return next == -1;
 }
 
 // ---- symbols of one block (T.81 F.1.2 with the reference's eager ZRL) --------------------

@@ -137,6 +137,35 @@ def test_config5_slice_batch_of_1080p(env):
     assert len(set(sums.tolist())) == n
 
 
+def test_config5_all_4096_images_of_1080p_on_one_gpu(env):
+    """BASELINE.json configs[4] in its stated size on ONE GPU (the N = 1 point of the sharded job: 25.5 GB of coefficients,
+    25.5 GB of pixels): 4096 independent 1920x1080 images in one call -- the ticket walk over 524 288 stacks, the mixed
+    column cut, 32-bit stack indices.  Eight images spread over the batch against the oracle, the same eight decoded again
+    one by one (a batch is its images), and a whole-batch witness: every image differs from every other one.
+    A GPU with less than 64 GB free runs the largest power of two that fits (>= 1024 images)."""
+    e = env
+    torch = e["torch"]
+    size, n = (1920, 1080), 4096
+    free, _ = torch.cuda.mem_get_info(e["ctx"].torch_device)
+    per_image = 2 * sum(64 * a * b for a, b in e["layout"].units(size)) + size[0] * size[1] * 3
+    while n > 1024 and n * per_image + (8 << 30) > free:
+        n //= 2
+    assert n * per_image + (4 << 30) <= free, "not enough device memory for 1024 images of 1080p"
+    planes = e["synth"].natural_planes_torch(e["layout"].units(size), n, e["ctx"].torch_device, 4096)
+    batch = _decode_batch(e, size, planes, n)
+    spread = [0, 1, n // 8 + 3, n // 2 - 1, n // 2, (5 * n) // 8 + 17, n - 2, n - 1]
+    for i in spread:
+        want = _oracle_rgb(e, [p[i].cpu().numpy() for p in planes], size)
+        assert (batch[i].cpu().numpy().reshape(-1, 3) == want).all(), f"image {i} of {n}"
+        single = _decode_batch(e, size, [p[i:i + 1] for p in planes], 1)[0]
+        assert torch.equal(single, batch[i]), f"image {i}: batch != single"
+    # whole-batch witness, in chunks (an int64 copy of the batch would not fit)
+    sums = torch.cat([batch[i:i + 256].to(torch.int64).sum(dim=1) for i in range(0, n, 256)]).cpu().numpy()
+    assert len(set(sums.tolist())) == n
+    del batch, planes
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("size", [(65535, 24), (24, 65535)], ids=["widest", "tallest"])
 def test_extreme_aspect_ratios_at_the_frame_header_limit(size):
     """The frame header stores width and height in 16 bits (decode.swift:793-800): the widest

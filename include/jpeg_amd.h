@@ -322,6 +322,17 @@ int jpeg_amd_decompress(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes,
                         jpeg_amd_color color, uint8_t *h_pixels, size_t pixel_capacity,
                         jpeg_amd_frame_info *info);
 
+/* Rectangular<Format>.decompress(stream:cosite:) for ANY JPEG.Format  (decode.swift:4367-4374; what
+ * examples/custom-color/main.swift:190-200 does with its 12-bit four-component format): JPEG bytes in host memory ->
+ * entropy decoding on the host (restart intervals on `nthreads` threads, <= 0: all cores) -> idct() + interleaved(cosite:)
+ * on the GPU -> the samples, uint16 [H][W][n], in host memory.  n = nrecognized, the first nrecognized components of the
+ * frame (0: all of them); the components behind them are non-recognised by the format (jpeg.swift:21-56): they take part in
+ * the image's scale and in nothing else.  Precision 1 .. 16, 1 .. 4 components, sequential or progressive, any sampling
+ * factors.  rect_capacity: the size of h_rect in samples (H * W * n are written; EINVAL if it is smaller). */
+int jpeg_amd_decompress_rectangular(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes, int cosited,
+                                    int nrecognized, int nthreads, uint16_t *h_rect, size_t rect_capacity,
+                                    jpeg_amd_frame_info *info);
+
 /* The same for n_images files of ONE frame geometry (a burst, the frames of an MJPEG stream):
  * `nthreads` host threads (<= 0: all cores) entropy-decode into pinned buffers, the device decodes
  * a chunk of images per launch.  h_pixels: image i at h_pixels + i * pixel_stride (0 = W*H*3).
@@ -407,6 +418,17 @@ int jpeg_amd_compress(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint8
                       int nscans, const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out,
                       size_t capacity,
                       size_t *nbytes);
+
+/* Rectangular<Format>.compress(stream:quanta:) for ANY JPEG.Format  (encode.swift:2031; examples/custom-color/
+ * main.swift:132-188): samples uint16 [H][W][frame->ncomponents] in host memory -> decomposed() + fdct(quanta:) on the GPU
+ * -> entropy coding on the host -> JPEG bytes.  frame: width, height, precision (1 .. 16), process, ncomponents (1 .. 4),
+ * id[] (ascending), factor_*[]; units_* and scale_* are filled in.  Tables, scans and metadata as for jpeg_amd_compress
+ * (quanta above 255 are written as 16-bit tables).  h_out == NULL only computes *nbytes. */
+int jpeg_amd_compress_rectangular(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint16_t *h_rect,
+                                  const int32_t *quanta_key, const uint16_t *h_quanta,
+                                  const int32_t *h_quanta_keys, int ntables, const jpeg_amd_scan *scans,
+                                  int nscans, const jpeg_amd_metadata *metadata, int nmetadata, uint8_t *h_out,
+                                  size_t capacity, size_t *nbytes);
 
 /* The same for n_images pictures of ONE geometry, tables and scan progression: image i at
  * h_pixels + i * pixel_stride (0 = W*H*3); file i is written to h_out + i * out_stride and is

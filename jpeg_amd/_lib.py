@@ -96,11 +96,13 @@ SIGNATURES = {
     "jpeg_amd_stream_info": (C.c_int, [_p, _p]),
     "jpeg_amd_stream_snapshot": (C.c_int, [_p, _pp, _p]),
     "jpeg_amd_decompress": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_int, _p, C.c_size_t, _p]),
+    "jpeg_amd_decompress_rectangular": (C.c_int, [_p, _p, C.c_size_t, C.c_int, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_decompress_batch": (C.c_int, [_p, _pp, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_decompress_batch_device": (C.c_int, [_p, _pp, _p, C.c_int, C.c_int, C.c_int, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_jpeg_encode_spectral": (C.c_int, [_p, _p, _pp, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_jpeg_encode_sparse": (C.c_int, [_p, _p, _p, _p, C.c_size_t, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_compress": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
+    "jpeg_amd_compress_rectangular": (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_compress_batch": (C.c_int, [_p, _p, _p, C.c_size_t, C.c_int, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int,
                                           C.c_int, _p, C.c_size_t, _p]),
     "jpeg_amd_compress_batch_device": (C.c_int, [_p, _p, _p, C.c_size_t, C.c_int, C.c_int, _p, _p, _p, C.c_int, _p, C.c_int, _p, C.c_int,

@@ -579,6 +579,66 @@ class Rectangular:
     def host_values(self) -> np.ndarray:
         return self.values.cpu().numpy().view(np.uint16)
 
+    # ---- the one-call forms of the C ABI for custom formats (host memory in, host memory out) --------------------------------
+    @staticmethod
+    def decompress_to_host(ctx: Context, source, cosite: bool = False, recognized: int = 0, threads: int = 0):
+        """Rectangular<Format>.decompress(stream:cosite:) for any JPEG.Format in ONE call of the C ABI
+        (jpeg_amd_decompress_rectangular; decode.swift:4367-4374): -> (frame info, uint16 array [H, W, n]).
+        recognized: how many of the frame's components the format recognises (0: all)."""
+        data = np.frombuffer(_file_bytes(source), np.uint8)
+        info = _lib.FrameInfo()
+        _lib.check(_lib.lib().jpeg_amd_jpeg_inspect(data.ctypes.data, data.size, C.byref(info)), "jpeg_amd_jpeg_inspect")
+        n = recognized or info.ncomponents
+        out = np.empty((info.height, info.width, n), np.uint16)
+        _lib.check(_lib.lib().jpeg_amd_decompress_rectangular(
+            ctx.handle, data.ctypes.data, data.size, 1 if cosite else 0, recognized, threads, out.ctypes.data, out.size,
+            C.byref(info)), "jpeg_amd_decompress_rectangular", ctx.handle)
+        return info, out
+
+    @staticmethod
+    def compress_from_host(ctx: Context, size, layout: "Layout", values, quanta: Dict[int, Sequence[int]], scans,
+                           process: str = "baseline", metadata=None, path=None, restart_interval: int = 0) -> bytes:
+        """Rectangular<Format>.compress(stream:quanta:) for any JPEG.Format in ONE call of the C ABI
+        (jpeg_amd_compress_rectangular; encode.swift:2031).  values: uint16 [H, W, count] in host memory."""
+        values = np.ascontiguousarray(np.asarray(values, np.uint16).reshape(int(size[1]), int(size[0]), layout.count))
+        info = _lib.FrameInfo()
+        info.width, info.height = int(size[0]), int(size[1])
+        info.precision, info.ncomponents = layout.precision, layout.count
+        info.process = {"baseline": 0, "extended": 1, "progressive": 2}[process]
+        info.restart_interval = int(restart_interval)
+        keys = []
+        for p, (key, comp) in enumerate(zip(layout.recognized, layout.planes)):
+            info.id[p] = int(key)
+            info.factor_x[p], info.factor_y[p] = comp.factor
+            keys.append(comp.qi)
+        tkeys = sorted(set(keys))
+        for k in tkeys:
+            if k not in quanta:
+                raise _lib.JpegAmdError(_lib.EINVAL, f"missing quantization table for quanta key {k}")
+        tables = np.stack([np.asarray(quanta[k], np.uint16).reshape(64) for k in tkeys])
+        qkey = (C.c_int32 * len(keys))(*keys)
+        tk = (C.c_int32 * len(tkeys))(*tkeys)
+        sarr = _scan_array(scans)
+        marr, nmeta, _keep = _metadata_array(metadata)
+        n = C.c_size_t()
+        # the entropy coder sizes its output from the coefficients: a first call without a buffer would run the kernels twice,
+        # so the buffer is sized generously instead (raw samples + headers) and the call repeated only if that was too small
+        cap = values.size * 2 + (1 << 16)
+        for _ in range(2):
+            out = np.empty(cap, np.uint8)
+            st = _lib.lib().jpeg_amd_compress_rectangular(ctx.handle, C.byref(info), values.ctypes.data, qkey, tables.ctypes.data, tk,
+                                                          len(tkeys), sarr, len(scans), marr, nmeta, out.ctypes.data, out.size, C.byref(n))
+            if st == _lib.EINVAL and n.value > cap:
+                cap = n.value
+                continue
+            _lib.check(st, "jpeg_amd_compress_rectangular", ctx.handle)
+            break
+        data = out[:n.value].tobytes()
+        if path is not None:
+            with open(path, "wb") as f:
+                f.write(data)
+        return data
+
 
 def compression_quanta(kind: str, level: float) -> np.ndarray:
     """JPEG.CompressionLevel.quanta (encode.swift:260-333): host-side constant tables,

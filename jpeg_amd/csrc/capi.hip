@@ -1053,6 +1053,46 @@ try {
 }
 JA_NOTHROW_TAIL
 
+
+// Rectangular<Format>.decompress(stream:cosite:) for any format (decode.swift:4367-4374): the one-call form of
+// jpeg_amd_jpeg_decode_spectral_mt + jpeg_amd_host_spectral_rectangular.
+int jpeg_amd_decompress_rectangular(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, size_t nbytes, int cosited, int nrecognized,
+                                    int nthreads, uint16_t *h_rect, size_t rect_capacity, jpeg_amd_frame_info *info_out)
+try {
+    JA_TRY(bind(ctx));
+    if (!h_jpeg) return JPEG_AMD_EINVAL;
+    jpeg_amd_frame_info fi;
+    JA_TRY(jpeg_amd_jpeg_inspect(h_jpeg, nbytes, &fi));
+    if (info_out) *info_out = fi;
+    const int nc = fi.ncomponents;
+    if (nc < 1 || nc > JPEG_AMD_MAX_PLANES || fi.precision < 1 || fi.precision > 16) return JPEG_AMD_ENOSUP;
+    if (nrecognized < 0 || nrecognized > nc) return JPEG_AMD_EINVAL;
+    const int np = nrecognized == 0 ? nc : nrecognized;
+    const size_t need = (size_t)fi.width * fi.height * np;
+    if (!h_rect || rect_capacity < need) return JPEG_AMD_EINVAL;
+    // every component is entropy-decoded (a scan may interleave recognised and non-recognised ones); only the recognised
+    // planes go to the device
+    std::vector<std::vector<int16_t>> planes((size_t)nc);
+    int16_t *coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int c = 0; c < nc; ++c) {
+        planes[c].resize((size_t)64 * fi.units_x[c] * fi.units_y[c]);
+        coef[c] = planes[c].data();
+    }
+    uint16_t quanta[JPEG_AMD_MAX_PLANES][64];
+    JA_TRY(jpeg_amd_jpeg_decode_spectral_mt(h_jpeg, nbytes, coef, quanta, &fi, nthreads));
+    if (info_out) *info_out = fi;
+    jpeg_amd_layout L{};
+    L.width = fi.width; L.height = fi.height; L.precision = fi.precision; L.nplanes = np;
+    L.scale_x = fi.scale_x; L.scale_y = fi.scale_y;          // the scale of ALL components (decode.swift:2181-2190)
+    for (int c = 0; c < np; ++c) {
+        L.factor_x[c] = fi.factor_x[c]; L.factor_y[c] = fi.factor_y[c];
+        L.units_x[c] = fi.units_x[c];   L.units_y[c] = fi.units_y[c];
+        L.qi[c] = c;
+    }
+    return jpeg_amd_host_spectral_rectangular(ctx, &L, coef, &quanta[0][0], np, cosited, h_rect);
+}
+JA_NOTHROW_TAIL
+
 // ---- many JPEG files of one geometry -> pixels: host threads entropy-decode a chunk into
 //      pinned memory while the device (H2D, fused decode, D2H on the context's stream) works on
 //      the previous chunk ----------------------------------------------------------------------
@@ -1394,6 +1434,45 @@ try {
         coef[c] = planes[c].data();
     }
     JA_TRY(jpeg_amd_host_encode(ctx, &L, h_pixels, color, h_quanta, ntables, coef));
+    return jpeg_amd_jpeg_encode_spectral(frame, quanta_key, coef, h_quanta, h_quanta_keys, ntables, scans, nscans,
+                                         metadata, nmetadata, h_out, capacity, nbytes);
+}
+JA_NOTHROW_TAIL
+
+
+// Rectangular<Format>.compress(stream:quanta:) for any format (encode.swift:2031): the one-call form of
+// jpeg_amd_host_rectangular_spectral + jpeg_amd_jpeg_encode_spectral.
+int jpeg_amd_compress_rectangular(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uint16_t *h_rect,
+                                  const int32_t *quanta_key, const uint16_t *h_quanta, const int32_t *h_quanta_keys, int ntables,
+                                  const jpeg_amd_scan *scans, int nscans, const jpeg_amd_metadata *metadata, int nmetadata,
+                                  uint8_t *h_out, size_t capacity, size_t *nbytes)
+try {
+    JA_TRY(bind(ctx));
+    if (!frame || !h_rect || !quanta_key || !h_quanta || !h_quanta_keys || !scans || !nbytes) return JPEG_AMD_EINVAL;
+    const int nc = frame->ncomponents;
+    if (nc < 1 || nc > JPEG_AMD_MAX_PLANES || frame->precision < 1 || frame->precision > 16) return JPEG_AMD_ENOSUP;
+    if (frame->width < 1 || frame->height < 1 || ntables < 1 || ntables > JPEG_AMD_MAX_PLANES) return JPEG_AMD_EINVAL;
+    jpeg_amd_layout L{};
+    L.width = frame->width; L.height = frame->height; L.precision = frame->precision; L.nplanes = nc;
+    L.scale_x = L.scale_y = 1;
+    for (int c = 0; c < nc; ++c) {
+        if (frame->factor_x[c] < 1 || frame->factor_y[c] < 1) return JPEG_AMD_EINVAL;
+        L.factor_x[c] = frame->factor_x[c]; L.factor_y[c] = frame->factor_y[c];
+        L.scale_x = std::max(L.scale_x, L.factor_x[c]); L.scale_y = std::max(L.scale_y, L.factor_y[c]);
+        L.qi[c] = -1;
+        for (int t = 0; t < ntables; ++t) if (h_quanta_keys[t] == quanta_key[c]) L.qi[c] = t;
+        if (L.qi[c] < 0) return JPEG_AMD_EINVAL;   // missing quantization table (decode.swift:2527)
+    }
+    JA_TRY(jpeg_amd_layout_units(&L));
+    frame->scale_x = L.scale_x; frame->scale_y = L.scale_y;
+    std::vector<std::vector<int16_t>> planes((size_t)nc);
+    int16_t *coef[JPEG_AMD_MAX_PLANES] = {};
+    for (int c = 0; c < nc; ++c) {
+        frame->units_x[c] = L.units_x[c]; frame->units_y[c] = L.units_y[c];
+        planes[c].resize((size_t)64 * L.units_x[c] * L.units_y[c]);
+        coef[c] = planes[c].data();
+    }
+    JA_TRY(jpeg_amd_host_rectangular_spectral(ctx, &L, h_rect, h_quanta, ntables, coef));
     return jpeg_amd_jpeg_encode_spectral(frame, quanta_key, coef, h_quanta, h_quanta_keys, ntables, scans, nscans,
                                          metadata, nmetadata, h_out, capacity, nbytes);
 }

@@ -2,7 +2,8 @@
 //
 // Replaces idct() -> interleaved(cosite:) (decode.swift:4154-4165, 4182-4276) for every layout the built-in 8-bit fast
 // paths do not take: any precision 1 .. 16 (examples/custom-color/main.swift:41-63 uses 12), one to four planes, centred or
-// cosited upsampling, every plane at the image's scale or at half of it per axis (factors 1 | 2 under a scale of at most 2).
+// cosited upsampling, every plane an integer fraction of the image's scale per axis: 1, 1/2, 1/3 or 1/4 (4:1:1, 4:1:0 and the
+// factor-3 layouts since round 6; a scale of at most 4).
 // Output: the reference's Rectangular, uint16 [H][W][count].  No Planar intermediate in HBM: 128 B per coefficient block in,
 // 2 B per sample out ("stops at Rectangular").
 //
@@ -44,6 +45,10 @@ struct GenPlane {
     int direct;           // factor == scale on both axes, or a single-plane image: cropped copy (decode.swift:4185-4215)
     int qi;
     int ax, bx, cx, ay, by, cy;   // decode.swift:4223-4234
+    int lgx, lgy;         // log2 of cx / cy where that is a power of two, else -1 ...
+    uint32_t mx, my;      // ... and then ceil(2^32 / c): the quotient by c = 3 or 6 is one v_mul_hi_u32 (exact below 2^26)
+    int fastx, fasty;     // the axis is at the image's scale or at exactly half of a scale of 2: the tile's block range and the
+                          // shared-sample fetch of phase B are known at compile time; otherwise they follow from (a, b, c)
 };
 struct GenArgs {
     GenPlane pl[JPEG_AMD_MAX_PLANES];
@@ -67,10 +72,13 @@ __device__ __forceinline__ float rounded_nonneg(float v)
     return r + __builtin_truncf(d + d);
 }
 
-// truncating division by c = 1, 2 or 4 (log2c = 0, 1, 2) -- Int.quotientAndRemainder, decode.swift:4240
-__device__ __forceinline__ int div_trunc_pow2(int n, int c, int log2c)
+// truncating division by c = 1 .. 8 -- Int.quotientAndRemainder, decode.swift:4240.  c a power of two (log2c >= 0): shifts; c = 3 or 6:
+// n is negative only for the image's first pixel (n = a = factor - scale > -c), where the quotient truncates to 0, and otherwise
+// below 2^26, where mulhi(n, ceil(2^32 / c)) IS the quotient.
+__device__ __forceinline__ int div_trunc_small(int n, int c, int log2c, uint32_t magic)
 {
-    return (n + ((n >> 31) & (c - 1))) >> log2c;
+    if (log2c >= 0) return (n + ((n >> 31) & (c - 1))) >> log2c;
+    return (int)__umulhi((uint32_t)max(n, 0), magic);
 }
 
 template <int TH, int COUNT>
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint16_t tile[kGThreads * 64];   // at most one block per work-item: 32 KiB
     __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                             // modulated tables (natural order)
-    __shared__ float tt[JPEG_AMD_MAX_PLANES][2][8];                           // t = clamp(Float(f) / Float(c)), f = -1 .. 6
+    __shared__ float tt[JPEG_AMD_MAX_PLANES][2][12];                          // t = clamp(Float(f) / Float(c)), f = -3 .. 8 (at index f + 3)
     __shared__ __attribute__((aligned(16))) uint32_t ostage[kGThreads / 64][4 * 64 * COUNT];   // per wave: 4 rows x 128 px x COUNT samples
 
     const int t = threadIdx.x, img = blockIdx.y;
@@ -89,11 +97,11 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
     {
         const int p = t >> 6, e = t & 63;
         if (p < COUNT) sq[p][e] = modulate_entry(e & 7, e >> 3, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.pl[p].qi + zigzag_of(e & 7, e >> 3)]);
-        if (t < JPEG_AMD_MAX_PLANES * 16) {
-            const int pp = t >> 4, axis = (t >> 3) & 1, f = (t & 7) - 1;
-            if (pp < COUNT) {
+        if (t < JPEG_AMD_MAX_PLANES * 32) {
+            const int pp = t >> 5, axis = (t >> 4) & 1, slot = t & 15, f = slot - 3;
+            if (pp < COUNT && slot < 12) {
                 const int c = axis ? a.pl[pp].cy : a.pl[pp].cx;
-                tt[pp][axis][t & 7] = fmaxf(0.0f, fminf((float)f / (float)c, 1.0f));   // decode.swift:4250-4251
+                tt[pp][axis][slot] = fmaxf(0.0f, fminf((float)f / (float)c, 1.0f));   // decode.swift:4250-4251
             }
         }
     }
@@ -103,10 +111,24 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
     first[0] = 0;
 #pragma unroll
     for (int p = 0; p < COUNT; ++p) {
-        const bool hx = !a.pl[p].direct && a.pl[p].rx == 2, hy = !a.pl[p].direct && a.pl[p].ry == 2;
-        bx0[p] = hx ? x0 / 16 - 1 : x0 / 8;  nbx[p] = hx ? GTW / 16 + 2 : GTW / 8;
-        by0[p] = hy ? y0 / 16 - 1 : y0 / 8;
-        const int nby = hy ? TH / 16 + 2 : TH / 8;
+        const GenPlane &P = a.pl[p];
+        int nby;
+        if (P.direct || P.fastx) {
+            const bool hx = !P.direct && P.rx == 2;
+            bx0[p] = hx ? x0 / 16 - 1 : x0 / 8;  nbx[p] = hx ? GTW / 16 + 2 : GTW / 8;
+        } else {   // the samples the tile's first and last pixel column read: i of the first, i + 1 of the last (decode.swift:4240-4246)
+            const int lo = div_trunc_small(P.ax + P.bx * x0, P.cx, P.lgx, P.mx);
+            const int hi = div_trunc_small(P.ax + P.bx * (x0 + GTW - 1), P.cx, P.lgx, P.mx) + 1;
+            bx0[p] = lo >> 3; nbx[p] = (hi >> 3) - bx0[p] + 1;
+        }
+        if (P.direct || P.fasty) {
+            const bool hy = !P.direct && P.ry == 2;
+            by0[p] = hy ? y0 / 16 - 1 : y0 / 8;  nby = hy ? TH / 16 + 2 : TH / 8;
+        } else {
+            const int lo = div_trunc_small(P.ay + P.by * y0, P.cy, P.lgy, P.my);
+            const int hi = div_trunc_small(P.ay + P.by * (y0 + TH - 1), P.cy, P.lgy, P.my) + 1;
+            by0[p] = lo >> 3; nby = (hi >> 3) - by0[p] + 1;
+        }
         first[p + 1] = first[p] + nbx[p] * nby;
     }
     __syncthreads();
@@ -177,13 +199,12 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
             } else {
                 const GenPlane &P = a.pl[p];
                 const int pw = 8 * P.ux, ph = 8 * P.uy;
-                const int lcx = P.cx == 4 ? 2 : P.cx == 2 ? 1 : 0, lcy = P.cy == 4 ? 2 : P.cy == 2 ? 1 : 0;
                 const int cols = pitch;
                 // the row's vertical position: decode.swift:4240-4251 for y
                 const int ny = P.ay + P.by * y;
-                const int iy = div_trunc_pow2(ny, P.cy, lcy), fy = ny - iy * P.cy;
+                const int iy = div_trunc_small(ny, P.cy, P.lgy, P.my), fy = ny - iy * P.cy;
                 const int jy = min(iy + 1, ph - 1);
-                const float ty = tt[p][1][fy + 1];
+                const float ty = tt[p][1][fy + 3];
                 const uint16_t *r0 = pt + (iy - oy) * pitch, *r1 = pt + (jy - oy) * pitch;
                 // The horizontal positions of 16 consecutive pixels starting at a multiple of 16 are known at compile time up
                 // to the plane's edge clamps: away from the edges the two sample rows are fetched ONCE as whole dwords (the 9 - 17
@@ -191,9 +212,10 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                 // on the same values as the per-pixel form below (decode.swift:4240-4264), which the threads at the plane's
                 // left / right edge keep.  kind: 0 a factor-2 axis, centred (a, b, c = -1, 2, 4: i = (2 x - 1) / 4, f = 3 | 1);
                 // 1 a factor-2 axis, cosited (0, 1, 2: i = x / 2, f = x & 1); 2 the axis is at the image's scale (i = x, f = 0).
+                // (only for an axis at the image's scale or at half of a scale of 2 -- P.fastx; every other ratio takes the per-pixel form)
                 const int kind = P.rx == 1 ? 2 : (P.cx == 4 ? 0 : 1);
                 const int seg = t & 7;
-                const bool away = kind == 2 || ((kind == 1 || xb >= 16) && (xb >> 1) + 8 <= pw - 1);
+                const bool away = P.fastx && (kind == 2 || ((kind == 1 || xb >= 16) && (xb >> 1) + 8 <= pw - 1));
                 if (away) {
                     auto pixels = [&](auto K) {
                         constexpr int KIND = decltype(K)::value;
@@ -208,7 +230,7 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                             u1[2 * d] = (float)(a1 & 0xffffu); u1[2 * d + 1] = (float)(a1 >> 16);
                         }
                         // t of even / odd pixels: Float(f) / Float(c), f = 3 | 1 (centred), 0 | 1 (cosited), 0 (full scale)
-                        const float te = tt[p][0][(KIND == 0 ? 3 : 0) + 1], to = tt[p][0][(KIND == 2 ? 0 : 1) + 1];
+                        const float te = tt[p][0][(KIND == 0 ? 3 : 0) + 3], to = tt[p][0][(KIND == 2 ? 0 : 1) + 3];
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             // index of sample i_x in the fetched window: centred floor((2 i - 1) / 4) + 2, cosited i / 2, full scale i
@@ -228,9 +250,9 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                 for (int i = 0; i < 16; ++i) {
                     const int x = xb + i;
                     const int nxx = P.ax + P.bx * x;
-                    const int ix = div_trunc_pow2(nxx, P.cx, lcx), fx = nxx - ix * P.cx;
+                    const int ix = div_trunc_small(nxx, P.cx, P.lgx, P.mx), fx = nxx - ix * P.cx;
                     const int jx = min(ix + 1, pw - 1);
-                    const float tx = tt[p][0][fx + 1];
+                    const float tx = tt[p][0][fx + 3];
                     // tile-local columns; pixels right of the image (never stored) and the weight-0 neighbour of a full-
                     // resolution axis may point past the tile: any finite sample will do there
                     const int lix = min(ix - ox, cols - 1), ljx = min(jx - ox, cols - 1);
@@ -368,24 +390,25 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
         *reinterpret_cast<uint4 *>(raw + row * RP + 8 * ch) = v;
     }
     __syncthreads();
-    // ---- phase A2: Rectangular.decomposed() from there into the plane tiles.  The sum of the 1, 2 or 4 samples under a plane
-    //      sample is below 2^24, so Float(sum) is exact, its quotient by 1, 2 or 4 is exact, and the truncation of that
-    //      quotient (encode.swift:404, :422) is the sum shifted right ----
+    // ---- phase A2: Rectangular.decomposed() from there into the plane tiles.  The sum of the 1, 2, 4, 8 or 16 samples under a plane
+    //      sample (a box of 1, 2 or 4 per axis: encode.swift:403) is below 2^24, so Float(sum) is exact, its quotient by a power of
+    //      two is exact, and the truncation of that quotient (encode.swift:404, :422) is the sum shifted right ----
     // (plane by plane: which plane a sample belongs to, and with it the shape of its box, is then the same for the whole wave --
     // per-lane selects are v_cndmask_b32, the one instruction that issues ten times slower than the rest)
 #pragma unroll
     for (int p = 0; p < COUNT; ++p) {
         const int rx = a.pl[p].rx, ry = a.pl[p].ry;
-        const int shift = rx == 2 ? 6 : 7;                    // the plane tile is 128 / rx samples wide: a power of two
+        const int lrx = rx == 4 ? 2 : rx == 2 ? 1 : 0, lry = ry == 4 ? 2 : ry == 2 ? 1 : 0;
+        const int shift = 7 - lrx;                            // the plane tile is 128 / rx samples wide: a power of two
         uint16_t *dst = tile + first[p];
         const int nsamples = first[p + 1] - first[p];
         for (int local = t; local < nsamples; local += kGThreads) {
             const int ly = local >> shift, lx = local & ((1 << shift) - 1);
             const uint16_t *box = raw + (ly * ry) * RP + (lx * rx) * COUNT + p;
-            uint32_t sum = box[0];
-            if (rx == 2) sum += box[COUNT];
-            if (ry == 2) { sum += box[RP]; if (rx == 2) sum += box[RP + COUNT]; }
-            dst[local] = (uint16_t)(sum >> ((rx == 2) + (ry == 2)));
+            uint32_t sum = 0;
+            for (int dy = 0; dy < ry; ++dy)                   // (wave-uniform trip counts)
+                for (int dx = 0; dx < rx; ++dx) sum += box[dy * RP + dx * COUNT];
+            dst[local] = (uint16_t)(sum >> (lrx + lry));
         }
     }
     __syncthreads();
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
         // the plane's parameters from a small LDS table indexed by p (a chain of per-lane selects would be 7 (COUNT - 1) v_cndmask_b32)
         const int4 pa = par[p][0], pb = par[p][1];
         const int b0 = pa.x, f0 = pa.y, wpx = pa.z, ux = pa.w, uy = pb.x, rx = pb.y, ry = pb.z;
-        const int shift = rx == 2 ? 3 : 4;                    // 16 / rx blocks per tile row
+        const int shift = rx == 4 ? 2 : rx == 2 ? 3 : 4;      // 16 / rx blocks per tile row
         const int local = blk - b0, lby = local >> shift, lbx = local & ((1 << shift) - 1);
         gbx = x0 / (8 * rx) + lbx; gby = y0 / (8 * ry) + lby;
         have = gbx < ux && gby < uy;
@@ -449,7 +472,7 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
 #pragma unroll
     for (int q = 0; q < COUNT; ++q) {
         const int nbx = tw[q] / 8, rx = a.pl[q].rx, ry = a.pl[q].ry, ux = a.pl[q].ux, uy = a.pl[q].uy;
-        const int shift = rx == 2 ? 3 : 4;                    // 16 / rx blocks per tile row
+        const int shift = rx == 4 ? 2 : rx == 2 ? 3 : 4;      // 16 / rx blocks per tile row
         int16_t *coef = a.pl[q].coef + img * a.pl[q].stride;
         const int bx0 = x0 / (8 * rx), by0 = y0 / (8 * ry);
         (void)nbx;
@@ -463,13 +486,20 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     }
 }
 
+// blocks of a plane along one axis of a tile of `extent` pixels: at most (k_generic_fused derives the exact range per tile)
+int axis_blocks(bool direct, int factor, int scale, int extent)
+{
+    if (direct || factor == scale) return extent / 8;
+    if (scale == 2) return extent / 16 + 2;                       // half of a scale of 2: the tile's blocks + a ring of one
+    const int samples = (extent * factor + scale - 1) / scale + 2;   // the samples `extent` pixels read, neighbours included ...
+    return (samples + 6) / 8 + 1;                                  // ... starting anywhere inside a block
+}
 int tile_blocks(const jpeg_amd_layout &L, int th)
 {
     int n = 0;
     for (int p = 0; p < L.nplanes; ++p) {
         const bool direct = L.nplanes == 1 || (L.factor_x[p] == L.scale_x && L.factor_y[p] == L.scale_y);
-        const bool hx = !direct && L.scale_x / L.factor_x[p] == 2, hy = !direct && L.scale_y / L.factor_y[p] == 2;
-        n += (hx ? GTW / 16 + 2 : GTW / 8) * (hy ? th / 16 + 2 : th / 8);
+        n += axis_blocks(direct, L.factor_x[p], L.scale_x, GTW) * axis_blocks(direct, L.factor_y[p], L.scale_y, th);
     }
     return n;
 }
@@ -479,10 +509,10 @@ int tile_blocks(const jpeg_amd_layout &L, int th)
 bool generic_fused_supported(const jpeg_amd_layout &L)
 {
     if (L.nplanes < 1 || L.nplanes > JPEG_AMD_MAX_PLANES || L.precision < 1 || L.precision > 16) return false;
-    if (L.scale_x < 1 || L.scale_x > 2 || L.scale_y < 1 || L.scale_y > 2) return false;
+    if (L.scale_x < 1 || L.scale_x > 4 || L.scale_y < 1 || L.scale_y > 4) return false;
     for (int p = 0; p < L.nplanes; ++p) {
         if (L.factor_x[p] < 1 || L.factor_y[p] < 1 || L.factor_x[p] > L.scale_x || L.factor_y[p] > L.scale_y) return false;
-        if (L.scale_x % L.factor_x[p] || L.scale_y % L.factor_y[p]) return false;
+        if (L.scale_x % L.factor_x[p] || L.scale_y % L.factor_y[p]) return false;   // (2 in 3, 3 in 4: the staged kernels)
     }
     if (L.width < 1 || L.height < 1 || (long long)L.width * L.height * L.nplanes >= (1LL << 40)) return false;
     return tile_blocks(L, 32) <= kGThreads;
@@ -509,6 +539,11 @@ hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd
             P.ax = L.factor_x[p] - L.scale_x; P.ay = L.factor_y[p] - L.scale_y;
             P.bx = 2 * L.factor_x[p]; P.by = 2 * L.factor_y[p]; P.cx = 2 * L.scale_x; P.cy = 2 * L.scale_y;
         }
+        auto log2_of = [](int c) { return c == 1 ? 0 : c == 2 ? 1 : c == 4 ? 2 : c == 8 ? 3 : -1; };
+        P.lgx = log2_of(P.cx); P.lgy = log2_of(P.cy);
+        P.mx = (uint32_t)((0x100000000ull + (uint64_t)P.cx - 1) / (uint64_t)P.cx); P.my = (uint32_t)((0x100000000ull + (uint64_t)P.cy - 1) / (uint64_t)P.cy);
+        P.fastx = P.rx == 1 || (P.rx == 2 && L.scale_x == 2);
+        P.fasty = P.ry == 1 || (P.ry == 2 && L.scale_y == 2);
     }
     if (n_images == 0) return hipSuccess;
     const int th = tile_blocks(L, 64) <= kGThreads ? 64 : 32;
@@ -530,6 +565,10 @@ hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd
 
 bool generic_encode_supported(const jpeg_amd_layout &L)
 {
+    // the box of decomposed() spans 1, 2 or 4 samples per axis here (a box of 3 would need tiles 24 k pixels wide and a true
+    // division of its sum: those layouts take the staged kernels)
+    for (int p = 0; p < L.nplanes; ++p)
+        if (L.factor_x[p] >= 1 && L.factor_y[p] >= 1 && (L.scale_x / L.factor_x[p] == 3 || L.scale_y / L.factor_y[p] == 3)) return false;
     return generic_fused_supported(L) && (long long)L.width * L.height * L.nplanes < (1LL << 40);
 }
 

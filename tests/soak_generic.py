@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Soak of k_generic_fused (jpeg_amd_spectral_rectangular): random custom formats the fused kernel takes -- 1..4 planes, every
-factor 1 | 2, precision 1..16, centred / cosited, a non-recognised component setting the scale now and then -- on images of
+"""Soak of k_generic_fused (jpeg_amd_spectral_rectangular): random custom formats -- 1..4 planes, every factor 1 .. 4 (round 6:
+the fused kernels take every plane that is an integer fraction of the scale, the staged kernels the rest inside the same call),
+precision 1..16, centred / cosited, a non-recognised component setting the scale now and then -- on images of
 several tiles (up to 900 x 500), extreme and sparse coefficients, against the oracle (the reference's literal formulas).
     python tests/soak_generic.py <seed> <cases>   (not collected by pytest; uses the oracle)"""
 import os, sys
@@ -21,9 +22,11 @@ for it in range(N):
     elif kind == 1: w, h = 128 * int(rng.integers(1, 6)), 64 * int(rng.integers(1, 6))       # whole tiles
     elif kind == 2: w, h = 128 * int(rng.integers(1, 5)) + int(rng.integers(-17, 18)), 64 * int(rng.integers(1, 5)) + int(rng.integers(-17, 18))
     else: w, h = int(rng.integers(1, 40)), int(rng.integers(1, 40))
-    comps = {i + 1: J.Component((int(rng.integers(1, 3)), int(rng.integers(1, 3))), int(rng.integers(0, 2))) for i in range(n)}
+    fmax = int(rng.choice([2, 2, 3, 4, 4]))   # factors up to 2 (the layouts of round 5), 3 or 4
+    pick = (lambda: int(rng.choice([f for f in (1, 2, 3, 4) if f <= fmax])))
+    comps = {i + 1: J.Component((pick(), pick()), int(rng.integers(0, 2))) for i in range(n)}
     if n > 1 and rng.integers(4) == 0:   # (a single plane below the scale does not cover the image: the reference traps)
-        comps[99] = J.Component((2, 2), 0)    # not recognised: takes part in the scale only (decode.swift:2181-2190)
+        comps[99] = J.Component((fmax if rng.integers(2) else 2, fmax if rng.integers(2) else 2), 0)    # not recognised: takes part in the scale only (decode.swift:2181-2190)
     layout = J.Layout(("custom", precision, n), comps)
     units = layout.units((w, h))
     amp = 1 << (precision + 1)

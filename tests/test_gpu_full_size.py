@@ -159,8 +159,10 @@ def test_config5_all_4096_images_of_1080p_on_one_gpu(env):
         assert (batch[i].cpu().numpy().reshape(-1, 3) == want).all(), f"image {i} of {n}"
         single = _decode_batch(e, size, [p[i:i + 1] for p in planes], 1)[0]
         assert torch.equal(single, batch[i]), f"image {i}: batch != single"
-    # whole-batch witness, in chunks (an int64 copy of the batch would not fit)
-    sums = torch.cat([batch[i:i + 256].to(torch.int64).sum(dim=1) for i in range(0, n, 256)]).cpu().numpy()
+    # whole-batch witness, in chunks (an int64 copy of the batch would not fit): a position-weighted checksum per image
+    # (plain byte sums of 4096 images collide by chance)
+    weights = (torch.arange(size[0] * size[1] * 3, device=batch.device, dtype=torch.int64) % 65521) + 1
+    sums = torch.cat([(batch[i:i + 64].to(torch.int64) * weights).sum(dim=1) for i in range(0, n, 64)]).cpu().numpy()
     assert len(set(sums.tolist())) == n
     del batch, planes
     torch.cuda.empty_cache()

@@ -94,4 +94,6 @@ run("4:2:0 8-bit cosited -> Rect16", ("custom", 8, 3), {1: c((2, 2), 0), 2: c((1
 run("4:2:0 8-bit centred -> Rect16", ("custom", 8, 3), {1: c((2, 2), 0), 2: c((1, 1), 1), 3: c((1, 1), 1)}, False)
 run("4:4:4 16-bit, 3 planes", ("custom", 16, 3), {1: c((1, 1), 0), 2: c((1, 1), 1), 3: c((1, 1), 1)}, False)
 run("4:2:2 12-bit, 3 planes", ("custom", 12, 3), {1: c((2, 1), 0), 2: c((1, 1), 1), 3: c((1, 1), 1)}, False)
-run("4:1:1 8-bit (factor 4: staged only)", ("custom", 8, 3), {1: c((4, 1), 0), 2: c((1, 1), 1), 3: c((1, 1), 1)}, False)
+run("4:1:1 8-bit (4,1) + (1,1) x 2", ("custom", 8, 3), {1: c((4, 1), 0), 2: c((1, 1), 1), 3: c((1, 1), 1)}, False)
+run("4:1:0 12-bit (4,2) + (1,1) x 2", ("custom", 12, 3), {1: c((4, 2), 0), 2: c((1, 1), 1), 3: c((1, 1), 1)}, False)
+run("factor 3: (3,3) + (1,1) x 2, 12-bit", ("custom", 12, 3), {1: c((3, 3), 0), 2: c((1, 1), 1), 3: c((1, 1), 1)}, False)

@@ -338,7 +338,10 @@ int jpeg_amd_decompress_rectangular(jpeg_amd_ctx *ctx, const uint8_t *h_jpeg, si
  * a chunk of images per launch.  h_pixels: image i at h_pixels + i * pixel_stride (0 = W*H*3).
  * This is the restart-interval / image-level parallelism of SURVEY.md 8f-1 on the host side.
  * h_pixels may be pageable (downloaded into the context's pinned slots, copied out by the host threads) or page-locked
- * (hipHostMalloc / hipHostRegister: downloaded straight into it). */
+ * (hipHostMalloc / hipHostRegister: downloaded straight into it).
+ * Threads: the calling thread directs (it submits chunks to the device and polls their events); `nthreads` threads beside it
+ * entropy-decode, and for pageable output up to min(nthreads, 16) more copy pixels out of the pinned slots -- all of them kept
+ * in the context between calls.  If no helper thread can be started the call runs synchronously on the calling thread. */
 int jpeg_amd_decompress_batch(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], const size_t nbytes[],
                               int n_images, int nthreads, int cosited, jpeg_amd_color color,
                               uint8_t *h_pixels, size_t pixel_stride, jpeg_amd_frame_info *info);

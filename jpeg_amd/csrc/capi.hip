@@ -1136,6 +1136,9 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
     // fit its arena, a progressive or a damaged one is decoded into planes as before and uploaded whole.
     // Arena: 24 entries per block (3/4 of the planes' bytes at most; only what is used is uploaded).
     const size_t arena = 24 * blocks, sparse_elems = blocks + arena;           // uint32 per image: [descriptors][entries]
+    // descriptors are 32-bit indices into the arena: a frame whose arena would not be addressable that way (24 * blocks + blocks
+    // >= 2^32: beyond 60 000 x 60 000 4:4:4) is decoded into planes
+    const bool sparse_ok = sparse_elems < 0xffffffffull;
     // slot layout: [coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk] [quanta x chunk][skip flags][record offsets][records ...] [pixels x chunk]
     // The middle part goes up in ONE copy per chunk: the tables, the per-image flags, where each image's sparse record
     // [descriptors][entries in use] begins, and the records themselves, packed one behind the other in the order the threads
@@ -1237,8 +1240,8 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
         // descriptor array holds and never writes past the arena, so a file of another geometry is caught afterwards.
         // (spare threads only help a file that has restart intervals; such a file is decoded into planes on `inner` threads)
         bool sparse_done = false;
-        if (inner == 1 || fi.restart_interval == 0) {
-            if (record.size() < sparse_elems) record.resize(sparse_elems);      // (this thread's, for the whole call)
+        if ((inner == 1 || fi.restart_interval == 0) && sparse_ok) {
+            if (record.size() < sparse_elems) record.resize(sparse_elems);      // (this thread's; kept in the context between calls, trimmed on the way out when huge)
             size_t n = 0;
             const int ss = jpeg_amd_jpeg_decode_sparse(h_jpeg[file], nbytes[file], record.data(), blocks, record.data() + blocks, arena, &n, quanta, &f);
             if (ss == JPEG_AMD_OK) {
@@ -1286,16 +1289,36 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
         Queue &q; WorkerPool &p;
         ~Stop() { { std::lock_guard<std::mutex> g(q.m); q.abort = true; } q.cv.notify_all(); p.finish(); }
     } stop{queue, pool};
-    pool.begin(t_n, [&](int index) { worker(ctx->records[(size_t)index]); }, t_n + 1);
-    if (pool.size() < 2) {                                   // not one thread to be had: this one decodes everything first
-        { std::lock_guard<std::mutex> g(queue.m); queue.open_chunks = nchunks; }
-        if (nchunks > 2) return JPEG_AMD_ENOMEM;             // (only two slots: more than two chunks need a second thread)
-        pool.finish();
-    }
+    // Not one helper thread to be had (thread creation failed when the pool was made): no parallel region; this thread decodes
+    // every chunk itself, in front of the chunk's submission -- synchronous, slower, but any number of chunks goes through.
+    const bool inline_decode = pool.size() < 2;
+    if (inline_decode && ctx->records.empty()) ctx->records.resize(1);
+    if (!inline_decode) pool.begin(t_n, [&](int index) { worker(ctx->records[(size_t)index]); }, t_n + 1);
+    // The threads' sparse records stay in the context between calls (a batch of 1080p files: 5 MB per thread); a call on huge
+    // frames leaves several hundred MB per thread behind, which is given back on the way out.
+    struct Trim {
+        std::vector<std::vector<uint32_t>> &r;
+        ~Trim() { for (auto &v : r) if (v.capacity() > ((size_t)16 << 20)) std::vector<uint32_t>().swap(v); }
+    } trim{ctx->records};
     for (int k = 0; k < nchunks && result == JPEG_AMD_OK; ++k) {
         const int slot = k & 1, base = k * chunk, m = std::min(chunk, n_images - base);
         char *host = static_cast<char *>(ctx->file_pinned[slot]);
         const uint8_t *skip = reinterpret_cast<const uint8_t *>(host + skip_off);
+        if (inline_decode) {
+            // pinned slot `slot` is free once the uploads of chunk k - 2 have read it
+            if (k >= 2) {
+                const hipError_t w = wait_event(ctx->file_decoded[slot]);
+                if (w != hipSuccess) { ctx->last_hip = (int)w; result = JPEG_AMD_EHIP; break; }
+                packed_end[slot].store(0);
+            }
+            for (int i = 0; i < m; ++i) {
+                int st;
+                try { st = decode_file(base + i, ctx->records[0]); } catch (...) { st = JPEG_AMD_ENOMEM; }
+                status_all[(size_t)(base + i)] = st;
+            }
+            std::lock_guard<std::mutex> g(queue.m);
+            queue.left[(size_t)k] = 0;
+        } else {
         // (like every failure inside this loop it leaves through the common tail below, which waits for both streams)
         // While the threads are in chunk k: chunk k + 1 goes into the pinned slot of chunk k - 1, which is free when that chunk's
         // kernels are done (submitted at the end of the last iteration) -- wait for them here, where this thread has nothing
@@ -1313,6 +1336,7 @@ int decompress_batch_impl(jpeg_amd_ctx *ctx, const uint8_t *const h_jpeg[], cons
             std::unique_lock<std::mutex> g(queue.m);
             queue.cv.wait(g, [&] { return queue.left[(size_t)k] == 0; });          // chunk k is decoded
         }
+        }   // (!inline_decode)
         for (int i = 0; i < m; ++i) if (status_all[(size_t)(base + i)] != JPEG_AMD_OK) result = status_all[(size_t)(base + i)];
         { const int ds = end_drain(); if (ds != JPEG_AMD_OK) result = ds; }   // chunk k - 1 is out of its pinned slot: chunk k + 1's download may land there
         // (downloads that go straight into the caller's buffer are not waited for by a copy out: the device slot's pixels of
@@ -1530,10 +1554,12 @@ int compress_batch_impl(jpeg_amd_ctx *ctx, jpeg_amd_frame_info *frame, const uin
     // nonzero coefficient, an eighth of the planes for a typical picture) and go to the writer in that form
     // (jpeg_amd_jpeg_encode_sparse); a picture whose entries do not fit its arena comes down as planes, like every picture of a
     // progressive frame.  Arena: 24 entries per block.
-    const bool sparse_down = frame->process != 2;
     size_t blocks = 0;
     for (int c = 0; c < nc; ++c) blocks += (size_t)L.units_x[c] * L.units_y[c];
     const size_t arena = 24 * blocks, sparse_elems = blocks + arena;           // uint32 per image: [descriptors][entries]
+    // descriptors are 32-bit indices into the arena: a frame whose arena would not be addressable that way (24 * blocks + blocks
+    // >= 2^32: beyond 60 000 x 60 000 4:4:4) comes down as planes
+    const bool sparse_down = frame->process != 2 && sparse_elems < 0xffffffffull;
     // slot layout (pinned and device alike): [pixels x chunk][coef plane 0 x chunk][plane 1 x chunk][plane 2 x chunk][sparse x chunk][counts]
     size_t coef_off[JPEG_AMD_MAX_PLANES] = {};
     size_t off = align256(npx * chunk);

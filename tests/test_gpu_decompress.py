@@ -297,3 +297,47 @@ def test_a_bad_file_in_the_middle_of_a_batch_fails_the_call_and_leaves_the_conte
         assert st == 0
         for i in (0, 39, 40, 69):
             assert G.sha(out[i * w * h * 3:(i + 1) * w * h * 3]) == G.entry(name)["gold"]["rgb_sha256"]
+
+
+def test_decompress_batch_without_a_single_helper_thread():
+    """a process that cannot start one more thread (RLIMIT_NPROC reached) used to get ENOMEM for batches of more than
+    two chunks; now the calling thread decodes every chunk itself in front of its submission.  In a fresh interpreter: context
+    first (the runtime's own threads exist by then), then the limit, then 70 files = three chunks, pageable output (so the copy
+    pool cannot start a thread either).  Root is exempt from the limit: skipped there."""
+    import os, subprocess, sys
+    if os.geteuid() == 0:
+        pytest.skip("RLIMIT_NPROC does not bind root")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, resource, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import _golden as G
+import jpeg_amd as J
+from jpeg_amd import _lib
+ctx = J.Context(0)
+lib = _lib.lib()
+names = ["color-sequential-1.jpg", "color-progressive-1.jpg", "color-sequential-restart.jpg"]
+names = [n for n in names if (G.entry(n)["width"], G.entry(n)["height"]) == (G.entry(names[0])["width"], G.entry(names[0])["height"])]
+files = [np.fromfile(G.path(G.entry(n)["file"]), np.uint8) for n in names]
+n = 70
+batch = [files[i %% len(files)] for i in range(n)]
+w, h = G.entry(names[0])["width"], G.entry(names[0])["height"]
+out = np.zeros(n * w * h * 3, np.uint8)
+ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in batch]); sizes = (C.c_size_t * n)(*[f.size for f in batch])
+resource.setrlimit(resource.RLIMIT_NPROC, (1, resource.getrlimit(resource.RLIMIT_NPROC)[1]))   # no new thread from here on
+import threading
+try:
+    t = threading.Thread(target=lambda: None); t.start(); t.join(); print("limit does not bind"); sys.exit(3)
+except RuntimeError:
+    pass
+st = lib.jpeg_amd_decompress_batch(ctx.handle, ptrs, sizes, n, 8, 0, J.RGB.code, out.ctypes.data, 0, None)
+assert st == 0, st
+for i in range(n):
+    assert G.sha(out[i * w * h * 3:(i + 1) * w * h * 3]) == G.entry(names[i %% len(names)])["gold"]["rgb_sha256"], i
+print("ok")
+''' % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    if r.returncode == 3:
+        pytest.skip("RLIMIT_NPROC does not bind in this environment")
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-300:], r.stderr[-800:])

@@ -476,6 +476,24 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
         except Exception as e:   # a side measurement must not take the bench line with it
             two_streams = {"error": repr(e)[:200]}
 
+    # the same 20-step window over a ring of EIGHT image sets (rounds 1-4 rotated over 8: 3.2 GB of mappings, beyond the GPU's TLB
+    # reach; the default ring is 4 since round 5 -- ADVICE r05: report the old footprint beside the new one so that rounds stay
+    # comparable).  Not part of `value`.
+    ring8 = None
+    if sustained is not None and wl.ring != 8:
+        try:
+            wl8 = make_workload("c3", 8192, 8192, 1, 8, d_quanta, 20240807 + 1000 * rank)
+            for _ in range(8 + args.warmup):
+                wl8.step()
+            sync()
+            w_s, _ = time_region(wl8, wl8.step, args.steps, sync, barrier)
+            ring8 = {"ring": 8, "steps": args.steps, "ms_per_step": round(w_s / args.steps * 1e3, 5),
+                     "frac_hbm": round(wl8.bytes / (w_s / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "the timed region repeated over 8 distinct image sets (the footprint of rounds 1-4's headline)"}
+            del wl8
+        except Exception as e:   # a side measurement must not take the bench line with it
+            ring8 = {"error": repr(e)[:200]}
+
     # ---- the sharded C5 job (BASELINE.json configs[4]) at EVERY N, measured collectively: the strong-scaling curve is built
     #      from this record's Mpixels_per_s; `value` above stays on one workload ----
     c5_job = None
@@ -554,6 +572,8 @@ def run(args, make_workload=None, backend="nccl", device_kind="cuda"):
                 result["extra"]["c3_sustained"] = sustained
             if two_streams:
                 result["extra"]["c3_two_streams"] = two_streams
+            if ring8:
+                result["extra"]["c3_ring8"] = ring8
             encode_case = result["extra"].pop("_c4_host_case", None)
             # what the vendor's device-to-device memcpy moves on THIS box (read + written bytes per
             # second), measured just now: the practical ceiling of a 1 : 1 read / write stream

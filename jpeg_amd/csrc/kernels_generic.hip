@@ -177,9 +177,10 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
     // ---- phase B: 16 consecutive pixels of a row per work-item and pass ----
 #pragma unroll 1
     for (int pass = 0; pass < TH / 32; ++pass) {
-        const int y = y0 + 32 * pass + (t >> 3);
-        int xb = x0 + 16 * (t & 7);
-        asm volatile("" : "+v"(xb));   // opaque per pass: what depends only on x would otherwise be hoisted out of the pass loop (~190 VGPRs)
+        int tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));   // opaque per pass: what depends only on the work-item's place would otherwise be hoisted out of the pass loop (~190 VGPRs)
+        const int y = y0 + 32 * pass + (tl >> 3);
+        const int xb = x0 + 16 * (tl & 7);
         uint32_t o[8 * COUNT];   // 16 pixels x COUNT samples, packed in pairs in the output's order
 #pragma unroll
         for (int i = 0; i < 8 * COUNT; ++i) o[i] = 0;
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                 // 1 a factor-2 axis, cosited (0, 1, 2: i = x / 2, f = x & 1); 2 the axis is at the image's scale (i = x, f = 0).
                 // (only for an axis at the image's scale or at half of a scale of 2 -- P.fastx; every other ratio takes the per-pixel form)
                 const int kind = P.rx == 1 ? 2 : (P.cx == 4 ? 0 : 1);
-                const int seg = t & 7;
-                const bool away = P.fastx && (kind == 2 || ((kind == 1 || xb >= 16) && (xb >> 1) + 8 <= pw - 1));
+                const int seg = tl & 7;
+                const bool away = P.fastx && P.lgy >= 0 && (kind == 2 || ((kind == 1 || xb >= 16) && (xb >> 1) + 8 <= pw - 1));
                 if (away) {
                     auto pixels = [&](auto K) {
                         constexpr int KIND = decltype(K)::value;
@@ -229,17 +230,38 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                             u0[2 * d] = (float)(a0 & 0xffffu); u0[2 * d + 1] = (float)(a0 >> 16);
                             u1[2 * d] = (float)(a1 & 0xffffu); u1[2 * d + 1] = (float)(a1 >> 16);
                         }
-                        // t of even / odd pixels: Float(f) / Float(c), f = 3 | 1 (centred), 0 | 1 (cosited), 0 (full scale)
-                        const float te = tt[p][0][(KIND == 0 ? 3 : 0) + 3], to = tt[p][0][(KIND == 2 ? 0 : 1) + 3];
+                        // The weights of these pixels are binary fractions -- horizontally t = 1/4 | 3/4 centred, 0 | 1/2 cosited, 0 at full
+                        // scale; vertically f / c with c = 1, 2, 4 or 8 -- and the samples integers below 2^16: every product and sum of
+                        // decode.swift:4260-4264 is then an exact binary fraction (at most 16 + 2 + 3 significant bits), i.e. the
+                        // reference's value is EXACTLY
+                        //     V / (SX * SY),   V = (cx0 u[ia] + cx1 u[ib]) of row i times cy0 + the same of row j times cy1
+                        // with small integer weights, whatever the order it is summed in -- and so is this evaluation: one FMA per row
+                        // (3 a + b; a + b or 2 a; a), one multiply and one FMA down the column, and .rounded() of the non-negative exact
+                        // value as the truncation of V / (SX SY) + 1/2 (exact as well; the conversion truncates).  Six operations per
+                        // pixel and plane where the literal sequence takes fourteen; the pixels at a plane's edge keep the literal one.
+                        // (This is arithmetic on exactly representable values, not a proof by exhaustion: it holds for every
+                        // precision up to 16 bits.  tests/soak_generic.py compares with the oracle's literal sequence.)
+                        constexpr float SXW = KIND == 0 ? 4.0f : KIND == 1 ? 2.0f : 1.0f;      // horizontal weights sum to this
+                        // vertical: t = clamp(f / c) with c a power of two up to 8 (this path is only taken then): weights f and c - f
+                        const float SYW = (float)P.cy;
+                        const float wy1 = (float)max(fy, 0);                                     // (f = a < 0 in the image's first row: t clamps to 0)
+                        const float wy0 = SYW - wy1;
+                        const float inv = __builtin_ldexpf(1.0f / SXW, -P.lgy);                  // 1 / (SXW * SYW): a power of two (wave-uniform)
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             // index of sample i_x in the fetched window: centred floor((2 i - 1) / 4) + 2, cosited i / 2, full scale i
                             const int ia = KIND == 0 ? (i == 0 ? 1 : (2 * i - 1) / 4 + 2) : KIND == 1 ? i / 2 : i;
-                            const int ib = KIND == 2 ? (i < 15 ? i + 1 : 15) : ia + 1;      // (full scale: the neighbour weighs 0)
-                            const float tx = (i & 1) ? to : te;
-                            const float v0 = u0[ia] * (1.0f - tx) + u0[ib] * tx;           // decode.swift:4260-4261
-                            const float v1 = u1[ia] * (1.0f - tx) + u1[ib] * tx;
-                            s[i] = (uint32_t)rounded_nonneg(v0 * (1.0f - ty) + v1 * ty);  // :4264
+                            const int ib = KIND == 2 ? (i < 15 ? i + 1 : 15) : ia + 1;
+                            float h0, h1;
+                            if constexpr (KIND == 0) {          // t = 3/4 (even pixels) | 1/4 (odd): 4 x value = u[ia] + 3 u[ib] | 3 u[ia] + u[ib]
+                                h0 = (i & 1) ? __builtin_fmaf(u0[ia], 3.0f, u0[ib]) : __builtin_fmaf(u0[ib], 3.0f, u0[ia]);
+                                h1 = (i & 1) ? __builtin_fmaf(u1[ia], 3.0f, u1[ib]) : __builtin_fmaf(u1[ib], 3.0f, u1[ia]);
+                            } else if constexpr (KIND == 1) {   // t = 0 (even) | 1/2 (odd): 2 x value = 2 u[ia] | u[ia] + u[ib]
+                                h0 = (i & 1) ? u0[ia] + u0[ib] : u0[ia] + u0[ia];
+                                h1 = (i & 1) ? u1[ia] + u1[ib] : u1[ia] + u1[ia];
+                            } else { h0 = u0[ia]; h1 = u1[ia]; (void)ib; }
+                            const float V = __builtin_fmaf(h0, wy0, h1 * wy1);
+                            s[i] = (uint32_t)__builtin_fmaf(V, inv, 0.5f);
                         }
                     };
                     if (kind == 0) pixels(std::integral_constant<int, 0>{});
@@ -273,13 +295,13 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
         //      touch 64 different 128-byte lines per instruction, 16 bytes each (partial-line writes: what k_encode_fused once spent a
         //      third of its time on).  Instead the wave's 8 rows x 128 pixels go to LDS four rows at a time and come back
         //      lane-linear: every store instruction writes 64 consecutive 16-byte chunks of whole row segments. ----
-        const int wv = t >> 6, lane = t & 63;
+        const int wv = tl >> 6, lane = tl & 63;
         uint32_t *st = ostage[wv];
         const int nvalid = min(GTW, a.W - x0) * COUNT;          // samples of a tile row inside the image
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if ((((t >> 3) & 4) >> 2) == h) {
-                uint4 *mine = reinterpret_cast<uint4 *>(st + ((t >> 3) & 3) * (64 * COUNT) + (t & 7) * (8 * COUNT));
+            if ((((tl >> 3) & 4) >> 2) == h) {
+                uint4 *mine = reinterpret_cast<uint4 *>(st + ((tl >> 3) & 3) * (64 * COUNT) + (tl & 7) * (8 * COUNT));
 #pragma unroll
                 for (int k = 0; k < 2 * COUNT; ++k) mine[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
             }
@@ -343,7 +365,8 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
 {
     __shared__ __attribute__((aligned(16))) uint16_t raw[GEW * GEH * COUNT];    // the tile of Rectangular; later the blocks on their way out
     extern __shared__ __attribute__((aligned(16))) uint16_t tile[];                // plane tiles: as many samples as the layout's planes have under a tile
-    __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                                // modulated tables (natural order, scale 8)
+    __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                                // modulated tables (natural order, scale 8) ...
+    __shared__ float sr[JPEG_AMD_MAX_PLANES][64];                                // ... and their correctly rounded reciprocals
     __shared__ int4 par[JPEG_AMD_MAX_PLANES][2];                                 // per plane: first block, first sample, tile width, units, ratios
 
     const int t = threadIdx.x, img = blockIdx.y;
@@ -351,7 +374,11 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     const int x0 = txi * GEW, y0 = tyi * GEH;
     {
         const int p = t >> 6, e = t & 63;
-        if (p < COUNT) sq[p][e] = modulate_entry(e & 7, e >> 3, 8.0f, a.quanta[img * a.quanta_stride + 64 * a.pl[p].qi + zigzag_of(e & 7, e >> 3)]);
+        if (p < COUNT) {
+            const float qv = modulate_entry(e & 7, e >> 3, 8.0f, a.quanta[img * a.quanta_stride + 64 * a.pl[p].qi + zigzag_of(e & 7, e >> 3)]);
+            sq[p][e] = qv;
+            sr[p][e] = 1.0f / qv;          // IEEE division: RN(1 / q)
+        }
     }
     // per plane (wave-uniform): the tile's sample rectangle and where it starts in LDS
     int tw[COUNT], th[COUNT], first[COUNT + 1], fb[COUNT + 1];
@@ -449,15 +476,32 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
             // the coefficients go straight to the staging area (the raw tile is no longer needed: every work-item is past the
             // barrier behind phase A2): int16 at its zigzag position z of block b, 16-byte chunk z / 8 at slot (z / 8) ^ (b & 7)
             uint16_t *mine = raw + 64 * blk;
+            // (opaque empty statements pin the program order: left alone, LLVM hoists the table reads of all eight columns over the
+            // arithmetic and spills -- kernels_encode.hip's fdct_quantise met the same)
+#pragma unroll
+            for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(f[i]));
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
+                __builtin_amdgcn_sched_barrier(0);
                 float r[8], res[8];
 #pragma unroll
                 for (int y = 0; y < 8; ++y) r[y] = f[8 * k + y];
                 fdct8<false>(r, 0.0f, res);
 #pragma unroll
                 for (int h = 0; h < 8; ++h) {
-                    const int32_t c = (int32_t)round_half_away(res[h] / sq[p][8 * h + k]);   // encode.swift:225-240
+                    // encode.swift:225-240: RN(H / q), rounded half away from zero.  The quotient as y0 = H r; e = fma(-y0, q, H);
+                    // y1 = fma(e, r, y0) with r = RN(1 / q) (Markstein's correction step) and the rounding as
+                    // trunc(y1 + copysign(pred(1/2), y1)): tools/verify_div16.hip proves by exhaustion on the GPU that the stored
+                    // integer equals the reference's for EVERY divisor a 16-bit table can produce (Q = 1 .. 65535, all 64
+                    // positions: 1.8 M divisors) and EVERY float numerator below 2^25 -- more than the FDCT of 16-bit samples
+                    // reaches (profiles/r06_verify_div16.txt).  Three operations instead of the ten of a true division.
+                    const float qq = sq[p][8 * h + k], rr = sr[p][8 * h + k];
+                    const float y0 = res[h] * rr;
+                    const float e1 = __builtin_fmaf(-y0, qq, res[h]);
+                    const float y1 = __builtin_fmaf(e1, rr, y0);
+                    const float hf = __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(0x7fffffffu, __builtin_bit_cast(uint32_t, 0.49999997f),
+                                                                                          __builtin_bit_cast(uint32_t, y1), 0xca));   // copysign(pred(1/2), y1)
+                    const int32_t c = (int32_t)(y1 + hf);
                     const int z = zigzag_of(k, h);
                     mine[8 * ((z >> 3) ^ (blk & 7)) + (z & 7)] = (uint16_t)c;
                 }

@@ -93,19 +93,6 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
     const int x0 = txi * GTW, y0 = tyi * TH;
 
-    // ---- tables: one entry per work-item (decode.swift:3984-4017), and the interpolation weights by a true division ----
-    {
-        const int p = t >> 6, e = t & 63;
-        if (p < COUNT) sq[p][e] = modulate_entry(e & 7, e >> 3, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.pl[p].qi + zigzag_of(e & 7, e >> 3)]);
-        if (t < JPEG_AMD_MAX_PLANES * 32) {
-            const int pp = t >> 5, axis = (t >> 4) & 1, slot = t & 15, f = slot - 3;
-            if (pp < COUNT && slot < 12) {
-                const int c = axis ? a.pl[pp].cy : a.pl[pp].cx;
-                tt[pp][axis][slot] = fmaxf(0.0f, fminf((float)f / (float)c, 1.0f));   // decode.swift:4250-4251
-            }
-        }
-    }
-
     // ---- the tile's blocks, plane by plane (wave-uniform scalars) ----
     int bx0[COUNT], by0[COUNT], nbx[COUNT], first[COUNT + 1];
     first[0] = 0;
@@ -131,18 +118,23 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
         }
         first[p + 1] = first[p] + nbx[p] * nby;
     }
-    __syncthreads();
 
-    // ---- phase A: dequantise + IDCT of one block, samples into the LDS tile ----
+    // ---- phase A, first half: the work-item's block (one of the blocks any plane contributes to the tile) is REQUESTED before
+    //      the tables are built: the two memory latencies at the head of a workgroup -- quanta, then coefficients -- overlap
+    //      (round 6; the waves of a tile spent 39 % of their cycles in s_waitcnt / the barriers: profiles/r06_pmc_generic.txt) ----
+    bool have = false;
+    uint32_t w[32];
+    int p = 0, f0 = 0, nx = 1, lbx = 0, lby = 0;
     if (t < first[COUNT]) {
-        int p = 0;
 #pragma unroll
         for (int q = 1; q < COUNT; ++q) p += t >= first[q];
-        int f0 = first[0], b0x = bx0[0], b0y = by0[0], nx = nbx[0];
+        int b0x = bx0[0], b0y = by0[0];
+        f0 = first[0]; nx = nbx[0];
 #pragma unroll
         for (int q = 1; q < COUNT; ++q)
             if (p == q) { f0 = first[q]; b0x = bx0[q]; b0y = by0[q]; nx = nbx[q]; }
-        const int local = t - f0, lby = local / nx, lbx = local - lby * nx;
+        const int local = t - f0;
+        lby = local / nx; lbx = local - lby * nx;
         const int gbx = b0x + lbx, gby = b0y + lby;
         int ux = a.pl[0].ux, uy = a.pl[0].uy;
         const int16_t *cbase = a.pl[0].coef + img * a.pl[0].stride;
@@ -150,13 +142,34 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
         for (int q = 1; q < COUNT; ++q)
             if (p == q) { ux = a.pl[q].ux; uy = a.pl[q].uy; cbase = a.pl[q].coef + img * a.pl[q].stride; }
         if (gbx >= 0 && gbx < ux && gby >= 0 && gby < uy) {   // blocks outside the plane are never read (index clamps below)
+            have = true;
             const uint4 *src = reinterpret_cast<const uint4 *>(cbase + (size_t)64 * ((size_t)gby * ux + gbx));
-            uint32_t w[32];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const uint4 v = src[i];
                 w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
             }
+        }
+    }
+
+    // ---- tables: one entry per work-item (decode.swift:3984-4017), and the interpolation weights by a true division ----
+    {
+        const int p = t >> 6, e = t & 63;
+        if (p < COUNT) sq[p][e] = modulate_entry(e & 7, e >> 3, 0.125f, a.quanta[img * a.quanta_stride + 64 * a.pl[p].qi + zigzag_of(e & 7, e >> 3)]);
+        if (t < JPEG_AMD_MAX_PLANES * 32) {
+            const int pp = t >> 5, axis = (t >> 4) & 1, slot = t & 15, f = slot - 3;
+            if (pp < COUNT && slot < 12) {
+                const int c = axis ? a.pl[pp].cy : a.pl[pp].cx;
+                tt[pp][axis][slot] = fmaxf(0.0f, fminf((float)f / (float)c, 1.0f));   // decode.swift:4250-4251
+            }
+        }
+    }
+
+    __syncthreads();
+
+    // ---- phase A: dequantise + IDCT of the block, samples into the LDS tile ----
+    {
+        if (have) {
             float g[64];
             idct_block(w, sq[p], a.level, g);
             uint16_t *dst = tile + 64 * f0 + (8 * lby) * (8 * nx) + 8 * lbx;

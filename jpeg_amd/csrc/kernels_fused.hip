@@ -104,7 +104,11 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     constexpr int HX = SX == 2 ? 4 : 0;                  // halo bytes per side
     constexpr int HY = SY == 2 ? 1 : 0;
     constexpr int PITCH = (CW + 2 * HX) / 4;             // dwords per LDS row
-    constexpr int ROWS = CR + 2 * HY;
+    // 4:4:0 (round 6): a wave's unit of work is a PAIR of vertically adjacent strips that share one chroma tile -- the sample row
+    // between them is the other strip's own first / last row, so only the pair's outer block rows need the edge-row pass:
+    // 2 + 1/3 transform passes per strip become 2 + 1/6.  No synchronisation: both strips belong to the same wave.
+    constexpr bool PAIR = CHROMA && SX == 1 && SY == 2;
+    constexpr int ROWS = (PAIR ? 2 : 1) * CR + 2 * HY;
     // 4:4:4: every work-item transforms the Cb and Cr blocks that lie under its luma block itself (same geometry),
     // parks their samples as bytes in 32 registers and then does the luma block
     constexpr bool INTHREAD = CHROMA && SX == 1 && SY == 1;
@@ -161,9 +165,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     auto rows_of = [&](const int16_t *plane, uint32_t row0, uint32_t nrows, uint32_t row_blocks) -> i32x4_t {
         return make_srd(reinterpret_cast<const char *>(plane) + ((uint64_t)(row0 * row_blocks) << 7), (nrows * row_blocks) << 7);
     };
-    auto dma_strip = [&](int s, int lane, int which = 0) {
-        int img, syi, sxi;
-        locate(s, img, syi, sxi);
+    // (the strip at strip row `syi`, strip column `sxi` of image `img`; `rows`, which == 3 only: the pair's strip rows, 1 or 2)
+    auto dma_at = [&](int img, int syi, int sxi, int lane, int which = 0, int rows = 1) {
         const uint32_t l3 = lane >> 3;
         const uint32_t ve = l3 * 128 + (((lane & 7) ^ (l3 >> 1)) << 4);  // even pieces; odd pieces: chunk ^ 4
         if constexpr (IN422 || IN440) {
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
             if (which == 3) {   // 4:4:0 halo: block b of the buffer: below b >> 5, plane (b >> 4) & 1, column b & 15
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int row = (u >> 1) ? 2 * syi + 2 : 2 * syi - 1;
+                    const int row = (u >> 1) ? 2 * syi + 2 * rows : 2 * syi - 1;   // below the unit's last strip / above its first
                     const bool there = row >= 0 && row < uyc;   // a missing row: an empty resource (zeros; the tile row is repaired below)
                     const i32x4_t srd = rows_of(a.ccoef[u & 1] + img * a.ccoef_stride[u & 1], there ? (uint32_t)row : 0u, there ? 1u : 0u, uxc);
                     lds_dma16_brun<2, false>(srd, (uint32_t)(16 * sxi) << 7, ve, ve ^ 64u, coef_lds + 2048 * u);
@@ -234,17 +237,29 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     int k = (int)blockIdx.x * NW + wave;
     if (k >= len) return;
     int s = strip_at(k);
-    dma_strip(s, lane0, INSTRIP ? 1 : 0);
+    // a unit is a strip -- or, 4:4:0, a pair of strip rows (locate() then yields the PAIR row): its strips are walked in turn
+    const int strips_y = (a.uy + BY - 1) / BY;
+    auto dma_unit_head = [&](int unit, int lane) {   // what a unit needs first: its (first strip's) chroma blocks, or its luma blocks
+        int img, uyi, sxi;
+        locate(unit, img, uyi, sxi);
+        dma_at(img, PAIR ? 2 * uyi : uyi, sxi, lane, INSTRIP ? 1 : 0);
+    };
+    dma_unit_head(s, lane0);
     int img_of_table = -1;
     int stores_behind_dma = 0;  // wave-uniform
     for (; k < len; k += nwaves, s = strip_at(min(k, len - 1))) {
+      int img, uyi, sxi;
+      locate(s, img, uyi, sxi);
+      const int syi0 = PAIR ? 2 * uyi : uyi;
+      const int nph = (PAIR && syi0 + 1 < strips_y) ? 2 : 1;   // strips of this unit
+#pragma unroll 1
+      for (int ph = 0; ph < nph; ++ph) {
         // Launder the lane id once per strip: everything below that depends only on the lane is
         // cheap to recompute, but hoisted out of this loop it would pin ~60 VGPRs for good.
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int lbx = lane & (BX - 1), seg = (int)((unsigned)lane / BX);
-        int img, syi, sxi;
-        locate(s, img, syi, sxi);
+        const int syi = syi0 + ph;
 
         // ---- modulated table (only when the image changes) ----
         if (img != img_of_table) {
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                dma_strip(s, lane, pl == 0 ? 2 : 0);
+                dma_at(img, syi, sxi, lane, pl == 0 ? 2 : 0);
                 float g[64];
                 idct_block(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, g);
                 {
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         if constexpr (IN422) {
             // pass 1: the strip's own chroma blocks (lane: plane, block row, block column)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dma_strip(s, lane, 2);
+            dma_at(img, syi, sxi, lane, 2);
             {
                 const int pl = lane >> 5, r = (lane >> 4) & 1, c = lane & 15;
                 float g[64];
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 }
                 // the block is in registers: the strip's luma blocks may follow it into the buffer
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                dma_strip(s, lane, 0);
+                dma_at(img, syi, sxi, lane, 0);
                 float edge[8];
                 idct_edge_col_split(cf, qv, 128.5f, side != 0, lane & 7, edge);
                 uint32_t e[8];
@@ -384,27 +399,32 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         }
 
         if constexpr (IN440) {
+          if (ph == 0) {   // the unit's first strip: the chroma tile of the whole unit (the second strip finds it ready)
             const int uyc = a.ph_c >> 3;
-            // pass 1: the strip's own chroma blocks (lane: plane, block row, block column) -> tile rows 1 .. 16
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dma_strip(s, lane, 3);
-            {
-                const int pl = lane >> 5, r = (lane >> 4) & 1, c = lane & 15;
-                float g[64];
-                idct_block(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, g);
-                uint32_t *dst = sc + pl * PLANE + (HY + 8 * r) * PITCH + 2 * c;
-                uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
-                trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
+            // the strips' own chroma blocks (lane: plane, block row, block column) -> tile rows 1 .. 16 (first strip), 17 .. 32 (second)
+#pragma unroll 1
+            for (int st = 0; st < nph; ++st) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (st + 1 < nph) dma_at(img, syi0 + 1, sxi, lane, 1);      // the second strip's chroma blocks ...
+                else dma_at(img, syi0, sxi, lane, 3, nph);                   // ... or the block rows above and below the unit
+                {
+                    const int pl = lane >> 5, r = (lane >> 4) & 1, c = lane & 15;
+                    float g[64];
+                    idct_block(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, g);
+                    uint32_t *dst = sc + pl * PLANE + (HY + CR * st + 8 * r) * PITCH + 2 * c;
+                    uint32_t pk[16];   // clamp [0, 255] + truncate (trunc_pack*, fused_common.hpp)
+                    trunc_pack24(g, pk); trunc_pack24(g + 24, pk + 6); trunc_pack16(g + 48, pk + 12);
 #pragma unroll
-                for (int y = 0; y < 8; ++y) { dst[y * PITCH] = pk[2 * y]; dst[y * PITCH + 1] = pk[2 * y + 1]; }
+                    for (int y = 0; y < 8; ++y) { dst[y * PITCH] = pk[2 * y]; dst[y * PITCH + 1] = pk[2 * y + 1]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                read_block();
             }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            read_block();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dma_strip(s, lane, 0);
-            // pass 2: the block rows above and below (lane: below, plane, column): the last / first sample row of each
-            // -> tile rows 0 and 17
+            dma_at(img, syi0, sxi, lane, 0);
+            // the block rows above and below the unit (lane: below, plane, column): the last / first sample row of each
+            // -> tile rows 0 and CR nph + 1
             {
                 const bool below = lane >= 32;
                 const int pl = (lane >> 4) & 1, c = lane & 15;
@@ -412,27 +432,28 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
                 idct_block_edge_row(w, TransposedTable{sqw[wave][1 + pl]}, 128.5f, (uint32_t)(lane - 32) & 0x80000000u, r8);   // above (lane < 32): the last row
                 uint32_t p01[2];
                 trunc_pack8(r8, p01);
-                if (below ? 2 * syi + 2 < uyc : syi > 0) {
-                    uint32_t *dst = sc + pl * PLANE + (below ? HY + CR : 0) * PITCH + 2 * c;
+                if (below ? 2 * syi0 + 2 * nph < uyc : syi0 > 0) {
+                    uint32_t *dst = sc + pl * PLANE + (below ? HY + CR * nph : 0) * PITCH + 2 * c;
                     dst[0] = p01[0]; dst[1] = p01[1];
                 }
             }
             // the plane's top and bottom: the reference clamps the sample row (decode.swift:4246) -- a missing row is the
             // nearest own row.  Only this wave reads its tile.
             {
-                const int rows_avail = a.ph_c - syi * CR;   // sample rows of the plane from the first one under this strip
+                const int rows_avail = a.ph_c - syi0 * CR;   // sample rows of the plane from the first one under the unit
                 auto copy_row = [&](int dstr, int srcr) {
                     for (int d = lane; d < 2 * PITCH; d += 64) {
                         uint32_t *col = sc + (d >= PITCH ? PLANE + d - PITCH : d);
                         col[dstr * PITCH] = col[srcr * PITCH];
                     }
                 };
-                if (syi == 0) copy_row(0, 1);
-                if (rows_avail > 0 && rows_avail <= CR) copy_row(rows_avail + 1, rows_avail);
+                if (syi0 == 0) copy_row(0, 1);
+                if (rows_avail > 0 && rows_avail <= CR * nph) copy_row(rows_avail + 1, rows_avail);
             }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             read_block();
+          }
         }
 
         // ---- luma: dequantise + IDCT, clamp + truncate (decode.swift:4121-4122), kept as
@@ -456,7 +477,8 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
 
         // ---- the coefficient buffer is consumed: prefetch the next strip into it.  From here to
         //      the end of the strip only stores are issued, so nothing waits on the DMA. ----
-        if (valid(k + nwaves)) dma_strip(strip_at(k + nwaves), lane, INSTRIP ? 1 : 0);
+        if (ph + 1 < nph) dma_at(img, syi + 1, sxi, lane, 0);                     // the unit's second strip: its luma blocks
+        else if (valid(k + nwaves)) dma_unit_head(strip_at(k + nwaves), lane);   // the next unit
         // keep the phases apart (hoisting the chroma LDS reads above the IDCT costs ~70 VGPRs)
         __builtin_amdgcn_sched_barrier(0);
 
@@ -466,7 +488,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         // ahead of their use -- a wave that waits ~150 cycles for LDS ten times per strip leaves its SIMD to
         // two other waves that are as likely to be waiting themselves.
         auto hraw = [&](int pl, int j, uint32_t (&r)[3]) {
-            const uint32_t *row = sc + pl * PLANE + (seg * (8 / SY) + j) * PITCH;
+            const uint32_t *row = sc + pl * PLANE + ((PAIR ? ph * CR : 0) + seg * (8 / SY) + j) * PITCH;
             if constexpr (SX == 2) {
                 r[0] = row[HX / 4 - 1 + lbx]; r[1] = row[HX / 4 + lbx]; r[2] = row[HX / 4 + 1 + lbx];
             } else if constexpr (INTHREAD) {   // the block's own samples, parked above
@@ -670,6 +692,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
         }
         __builtin_amdgcn_sched_barrier(0);
         store_row(7);
+      }   // strips of the unit
     }
 }
 
@@ -757,7 +780,9 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     const int sx = chroma ? L.scale_x : 1, sy = chroma ? L.scale_y : 1;
     const int bx = strip_width(la.ux, la.uy, sx, sy), by = 64 / bx;
     la.tiles_x = (la.ux + bx - 1) / bx;
-    la.tiles_per_image = la.tiles_x * ((la.uy + by - 1) / by);
+    const int strips_y = (la.uy + by - 1) / by;
+    const bool pairs = chroma && sx == 1 && sy == 2;           // 4:4:0: a unit of the walk is a pair of strip rows (k_luma_fused, PAIR)
+    la.tiles_per_image = la.tiles_x * (pairs ? (strips_y + 1) / 2 : strips_y);
     la.first_tile = 0;
     la.total_tiles = la.tiles_per_image * n_images;
     if (la.total_tiles == 0) return hipSuccess;

@@ -21,6 +21,14 @@ SOURCES = ["kernels_stage.hip", "kernels_fused.hip", "kernels_quad.hip", "kernel
 HEADERS = ["dct.hpp", "kernels.hpp", "upsample.hpp", "fused_common.hpp", "worker_pool.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-command-line-argument"]
+# Per-source flags.  The transform kernels are compiled WITHOUT the SLP vectoriser: it turns the float arithmetic of the 8-point
+# transforms into v_pk_*_f32 -- which issue at half rate (no gain per element), want their literal constants in registers and their
+# operands in aligned register pairs (459 v_mov_b32 in k_generic_fused<64, 3>).  Without it (round 6, one box, profiles/r06_no_slp.txt):
+# k_generic_fused 135 instead of 160 VGPRs and 5-10 % faster, k_idct_plane 96 instead of 164 VGPRs (100 k blocks 11.8 -> 11.3 us),
+# k_encode_fused 4096 x 4096 4:2:0 24.3-25.4 -> 23.4-23.6 us.  Same IEEE operations either way: results are bit-identical.
+# (k_quad420 / k_luma_fused pin their arithmetic with empty asm statements and hold no packed operations either way.)
+_NO_SLP = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {"kernels_generic.hip": _NO_SLP, "kernels_encode.hip": _NO_SLP, "kernels_stage.hip": _NO_SLP}
 
 
 # kernels that must not touch scratch memory: source -> mangled-name fragment.  The strip walks count their own VM operations
@@ -99,7 +107,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [cc, *FLAGS, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         if src in NO_SCRATCH or src in WARN_SCRATCH:

@@ -81,9 +81,21 @@ __device__ __forceinline__ int div_trunc_small(int n, int c, int log2c, uint32_t
     return (int)__umulhi((uint32_t)max(n, 0), magic);
 }
 
+// Development switches (never defined in the product build): JA_GEN_PHASE (tools/phase_generic.py: wall cycles of every 8th wave per
+// phase of its tile), JA_X_GEN_NOLOAD / JA_X_GEN_NOSTORE (the tile without its coefficient loads / its global stores).
+#ifdef JA_GEN_PHASE
+__device__ unsigned long long g_gen_phase[4096 * 16];
+#define GP_DECL unsigned long long gp_acc[16] = {}; unsigned long long gp_prev = __builtin_readcyclecounter(); const unsigned long long gp_first = gp_prev;
+#define GP(i) { const unsigned long long n_ = __builtin_readcyclecounter(); gp_acc[i] += n_ - gp_prev; gp_prev = n_; }
+#else
+#define GP_DECL
+#define GP(i)
+#endif
+
 template <int TH, int COUNT>
 __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
 {
+    GP_DECL
     __shared__ __attribute__((aligned(16))) uint16_t tile[kGThreads * 64];   // at most one block per work-item: 32 KiB
     __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                             // modulated tables (natural order)
     __shared__ float tt[JPEG_AMD_MAX_PLANES][2][12];                          // t = clamp(Float(f) / Float(c)), f = -3 .. 8 (at index f + 3)
@@ -146,11 +158,16 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
             const uint4 *src = reinterpret_cast<const uint4 *>(cbase + (size_t)64 * ((size_t)gby * ux + gbx));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+#ifdef JA_X_GEN_NOLOAD   // experiment: the tile without its coefficient loads
+                const uint4 v = make_uint4(t + i, gbx, gby, a.W < 0 ? src[i].x : 7u);
+#else
                 const uint4 v = src[i];
+#endif
                 w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
             }
         }
     }
+    GP(0)
 
     // ---- tables: one entry per work-item (decode.swift:3984-4017), and the interpolation weights by a true division ----
     {
@@ -165,7 +182,13 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
         }
     }
 
+    GP(1)
     __syncthreads();
+    GP(2)
+#ifdef JA_GEN_PHASE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GP(3)
+#endif
 
     // ---- phase A: dequantise + IDCT of the block, samples into the LDS tile ----
     {
@@ -185,7 +208,9 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
             }
         }
     }
+    GP(4)
     __syncthreads();
+    GP(5)
 
     // ---- phase B: 16 consecutive pixels of a row per work-item and pass ----
 #pragma unroll 1
@@ -253,7 +278,7 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                         // value as the truncation of V / (SX SY) + 1/2 (exact as well; the conversion truncates).  Six operations per
                         // pixel and plane where the literal sequence takes fourteen; the pixels at a plane's edge keep the literal one.
                         // (This is arithmetic on exactly representable values, not a proof by exhaustion: it holds for every
-                        // precision up to 16 bits.  tests/soak_generic.py compares with the oracle's literal sequence.)
+                        // precision up to 16 bits.  tests/soak_generic.py compares with the literal sequence, evaluated on the CPU.)
                         constexpr float SXW = KIND == 0 ? 4.0f : KIND == 1 ? 2.0f : 1.0f;      // horizontal weights sum to this
                         // vertical: t = clamp(f / c) with c a power of two up to 8 (this path is only taken then): weights f and c - f
                         const float SYW = (float)P.cy;
@@ -308,6 +333,7 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
         //      touch 64 different 128-byte lines per instruction, 16 bytes each (partial-line writes: what k_encode_fused once spent a
         //      third of its time on).  Instead the wave's 8 rows x 128 pixels go to LDS four rows at a time and come back
         //      lane-linear: every store instruction writes 64 consecutive 16-byte chunks of whole row segments. ----
+        GP(6)
         const int wv = tl >> 6, lane = tl & 63;
         uint32_t *st = ostage[wv];
         const int nvalid = min(GTW, a.W - x0) * COUNT;          // samples of a tile row inside the image
@@ -328,7 +354,11 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                 const int g = 64 * k + lane, row = g / (16 * COUNT), cc = g - row * (16 * COUNT);
                 const uint4 v = *reinterpret_cast<const uint4 *>(st + 4 * g);
                 const int yy = y0 + 32 * pass + 8 * wv + 4 * h + row;
+#ifdef JA_X_GEN_NOSTORE   // experiment: the tile without its global stores
+                if (a.W < 0 || (v.x == 0x12345678u && v.y == 0x9abcdef0u)) {
+#else
                 if (yy < a.H && 8 * cc < nvalid) {
+#endif
                     uint16_t *dst = a.out + img * a.out_stride + ((size_t)yy * a.W + x0) * COUNT + 8 * cc;
                     if (8 * cc + 8 <= nvalid) {
                         *reinterpret_cast<uint4 *>(dst) = v;      // (rows need not be 16-byte aligned: the hardware takes unaligned dwordx4 stores)
@@ -340,7 +370,16 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
             }
             __builtin_amdgcn_wave_barrier();   // ... and the next group's writes stay behind these reads
         }
+        GP(7)
     }
+#ifdef JA_GEN_PHASE
+    {
+        const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+        gp_acc[14] = __builtin_readcyclecounter() - gp_first;
+        if ((threadIdx.x & 63) == 0 && (wid & 7) == 0 && (wid >> 3) < 4096)
+            for (int i = 0; i < 16; ++i) g_gen_phase[(wid >> 3) * 16 + i] = gp_acc[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -355,6 +394,14 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
 // work-item from the LDS tile -- at most 64 per plane, 256 for four planes at full scale.  Phase C: the blocks' 128 bytes go
 // back through the same LDS (chunk-swizzled) and leave as whole runs of neighbouring blocks: every store instruction writes
 // 64 consecutive 16-byte chunks instead of 64 chunks 128 bytes apart.
+#ifdef JA_GEN_PHASE
+}  // namespace
+extern "C" int jpeg_amd_debug_gen_phase(unsigned long long *h_out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gen_phase), n * sizeof(unsigned long long));
+}
+namespace {
+#endif
 constexpr int GEW = 128;   // tile width in pixels; its height GEH is 32, or 64 where the blocks under 64 rows still fit 256 work-items
 
 struct GenEncPlane {

@@ -7,7 +7,8 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 out=tools/exp/obj_$name; mkdir -p $out
 for f in kernels_stage.hip kernels_fused.hip kernels_quad.hip kernels_encode.hip kernels_generic.hip capi.hip entropy.cpp entropy_encode.cpp; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I include "$@" -c jpeg_amd/csrc/$f -o $out/${f%.*}.o 2> $out/${f%.*}.log &
+  extra=""; case $f in kernels_generic.hip|kernels_encode.hip|kernels_stage.hip) extra="-fno-slp-vectorize";; esac   # (jpeg_amd/build.py EXTRA_FLAGS)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC $extra -I include "$@" -c jpeg_amd/csrc/$f -o $out/${f%.*}.o 2> $out/${f%.*}.log &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/exp/libjpeg_amd_$name.so $out/*.o

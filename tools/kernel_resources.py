@@ -3,7 +3,10 @@
     tools/kernel_resources.py jpeg_amd/csrc/kernels_encode.hip [-DMACRO ...]"""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-I", os.path.join(root, "include"),
+sys.path.insert(0, root)
+from jpeg_amd.build import EXTRA_FLAGS   # per-source flags of the product build
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", *EXTRA_FLAGS.get(os.path.basename(sys.argv[1]), []),
+       "-I", os.path.join(root, "include"),
        "--cuda-device-only", "-c", sys.argv[1], "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", *sys.argv[2:]]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, rows = None, {}

@@ -49,6 +49,9 @@ struct GenPlane {
     uint32_t mx, my;      // ... and then ceil(2^32 / c): the quotient by c = 3 or 6 is one v_mul_hi_u32 (exact below 2^26)
     int fastx, fasty;     // the axis is at the image's scale or at exactly half of a scale of 2: the tile's block range and the
                           // shared-sample fetch of phase B are known at compile time; otherwise they follow from (a, b, c)
+    float fcy;            // Float(cy), and (cy a power of two) 1 / (s cy) for s = 4, 2, 1: the exact filter's weights and scale come as
+    float inv_cy[3];      // kernel arguments -- computed in the kernel they are wave-uniform VALU results, hoisted out of the pass loop
+                          // into registers the four-wave build does not have (six spilled, every reload a vmcnt(0))
 };
 struct GenArgs {
     GenPlane pl[JPEG_AMD_MAX_PLANES];
@@ -92,14 +95,20 @@ __device__ unsigned long long g_gen_phase[4096 * 16];
 #define GP(i)
 #endif
 
+// Waves per SIMD = workgroups per CU.  Up to three planes: FOUR (round 6) -- 40 KiB of LDS with the output staged two pixel rows at a
+// time, and <= 128 VGPRs since the kernels are built without the SLP vectoriser (jpeg_amd/build.py) and the filter's wave-uniform
+// floats arrive as kernel arguments: 4:4:4 16-bit 188 -> 172 us, 4:2:2 12-bit 252 -> 230, 4:1:1 233 -> 222 (8192 x 8192,
+// profiles/r06_generic_four_waves.txt).  Four planes: three (42-50 KiB), staged four rows at a time.
+template <int COUNT> constexpr int generic_waves_per_simd() { return COUNT == 4 ? 3 : 4; }
 template <int TH, int COUNT>
-__global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
+__global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void k_generic_fused(GenArgs a)
 {
+    constexpr int SROWS = COUNT == 4 ? 4 : 2;   // pixel rows a wave stages at a time
     GP_DECL
     __shared__ __attribute__((aligned(16))) uint16_t tile[kGThreads * 64];   // at most one block per work-item: 32 KiB
     __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                             // modulated tables (natural order)
     __shared__ float tt[JPEG_AMD_MAX_PLANES][2][12];                          // t = clamp(Float(f) / Float(c)), f = -3 .. 8 (at index f + 3)
-    __shared__ __attribute__((aligned(16))) uint32_t ostage[kGThreads / 64][4 * 64 * COUNT];   // per wave: 4 rows x 128 px x COUNT samples
+    __shared__ __attribute__((aligned(16))) uint32_t ostage[kGThreads / 64][SROWS * 64 * COUNT];   // per wave: SROWS rows x 128 px x COUNT samples
 
     const int t = threadIdx.x, img = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
@@ -281,10 +290,11 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
                         // precision up to 16 bits.  tests/soak_generic.py compares with the literal sequence, evaluated on the CPU.)
                         constexpr float SXW = KIND == 0 ? 4.0f : KIND == 1 ? 2.0f : 1.0f;      // horizontal weights sum to this
                         // vertical: t = clamp(f / c) with c a power of two up to 8 (this path is only taken then): weights f and c - f
-                        const float SYW = (float)P.cy;
+                        const float SYW = P.fcy;
                         const float wy1 = (float)max(fy, 0);                                     // (f = a < 0 in the image's first row: t clamps to 0)
                         const float wy0 = SYW - wy1;
-                        const float inv = __builtin_ldexpf(1.0f / SXW, -P.lgy);                  // 1 / (SXW * SYW): a power of two (wave-uniform)
+                        const float inv = P.inv_cy[KIND];                                        // 1 / (SXW * SYW): a power of two (wave-uniform)
+                        (void)SXW;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             // index of sample i_x in the fetched window: centred floor((2 i - 1) / 4) + 2, cosited i / 2, full scale i
@@ -338,9 +348,9 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
         uint32_t *st = ostage[wv];
         const int nvalid = min(GTW, a.W - x0) * COUNT;          // samples of a tile row inside the image
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if ((((tl >> 3) & 4) >> 2) == h) {
-                uint4 *mine = reinterpret_cast<uint4 *>(st + ((tl >> 3) & 3) * (64 * COUNT) + (tl & 7) * (8 * COUNT));
+        for (int h = 0; h < 8 / SROWS; ++h) {
+            if (((tl >> 3) & 7) / SROWS == h) {
+                uint4 *mine = reinterpret_cast<uint4 *>(st + ((tl >> 3) & (SROWS - 1)) * (64 * COUNT) + (tl & 7) * (8 * COUNT));
 #pragma unroll
                 for (int k = 0; k < 2 * COUNT; ++k) mine[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
             }
@@ -350,10 +360,11 @@ __global__ __launch_bounds__(kGThreads, 3) void k_generic_fused(GenArgs a)
             // wave's operations in order.
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < COUNT; ++k) {          // 4 rows x 16 COUNT chunks = 64 COUNT chunks, lane-linear
+            for (int k = 0; k < (SROWS * COUNT + 3) / 4; ++k) {          // SROWS rows x 16 COUNT chunks, lane-linear
                 const int g = 64 * k + lane, row = g / (16 * COUNT), cc = g - row * (16 * COUNT);
+                if (SROWS * COUNT % 4 != 0 && g >= SROWS * 16 * COUNT) continue;
                 const uint4 v = *reinterpret_cast<const uint4 *>(st + 4 * g);
-                const int yy = y0 + 32 * pass + 8 * wv + 4 * h + row;
+                const int yy = y0 + 32 * pass + 8 * wv + SROWS * h + row;
 #ifdef JA_X_GEN_NOSTORE   // experiment: the tile without its global stores
                 if (a.W < 0 || (v.x == 0x12345678u && v.y == 0x9abcdef0u)) {
 #else
@@ -648,6 +659,8 @@ hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd
         P.mx = (uint32_t)((0x100000000ull + (uint64_t)P.cx - 1) / (uint64_t)P.cx); P.my = (uint32_t)((0x100000000ull + (uint64_t)P.cy - 1) / (uint64_t)P.cy);
         P.fastx = P.rx == 1 || (P.rx == 2 && L.scale_x == 2);
         P.fasty = P.ry == 1 || (P.ry == 2 && L.scale_y == 2);
+        P.fcy = (float)P.cy;
+        for (int k = 0; k < 3; ++k) P.inv_cy[k] = P.lgy >= 0 ? ldexpf(k == 0 ? 0.25f : k == 1 ? 0.5f : 1.0f, -P.lgy) : 0.0f;
     }
     if (n_images == 0) return hipSuccess;
     const int th = tile_blocks(L, 64) <= kGThreads ? 64 : 32;

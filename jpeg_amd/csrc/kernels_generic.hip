@@ -439,6 +439,7 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     __shared__ float sq[JPEG_AMD_MAX_PLANES][64];                                // modulated tables (natural order, scale 8) ...
     __shared__ float sr[JPEG_AMD_MAX_PLANES][64];                                // ... and their correctly rounded reciprocals
     __shared__ int4 par[JPEG_AMD_MAX_PLANES][2];                                 // per plane: first block, first sample, tile width, units, ratios
+    GP_DECL
 
     const int t = threadIdx.x, img = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
         par[t][0] = make_int4(fb[t], first[t], tw[t], a.pl[t].ux);
         par[t][1] = make_int4(a.pl[t].uy, a.pl[t].rx, a.pl[t].ry, 0);
     }
+    GP(0)
     // ---- phase A1: the tile of Rectangular as it lies in memory -> LDS, 16 bytes per work-item and step; a sample beyond the
     //      image is the nearest one inside (encode.swift:415-417: the box clamps its indices), fetched one at a time ----
     const uint16_t *rect = a.rect + img * a.rect_stride;
@@ -487,29 +489,62 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
         }
         *reinterpret_cast<uint4 *>(raw + row * RP + 8 * ch) = v;
     }
+    GP(1)
     __syncthreads();
+    GP(2)
     // ---- phase A2: Rectangular.decomposed() from there into the plane tiles.  The sum of the 1, 2, 4, 8 or 16 samples under a plane
     //      sample (a box of 1, 2 or 4 per axis: encode.swift:403) is below 2^24, so Float(sum) is exact, its quotient by a power of
     //      two is exact, and the truncation of that quotient (encode.swift:404, :422) is the sum shifted right ----
     // (plane by plane: which plane a sample belongs to, and with it the shape of its box, is then the same for the whole wave --
     // per-lane selects are v_cndmask_b32, the one instruction that issues ten times slower than the rest)
+    // A work-item takes the samples under EIGHT consecutive pixels of a raw row -- 8, 4 or 2 of them (round 6; one sample per work-item
+    // and step, 16-bit LDS reads and writes, was a third of a wave's life: tools/phase_generic.py): the eight pixels are COUNT whole
+    // 16-byte chunks (for three components 48 bytes from work-item to work-item: no bank conflict), the component is picked out of
+    // the registers by constant index, the results leave as one 16-, 8- or 4-byte write.
 #pragma unroll
     for (int p = 0; p < COUNT; ++p) {
         const int rx = a.pl[p].rx, ry = a.pl[p].ry;
         const int lrx = rx == 4 ? 2 : rx == 2 ? 1 : 0, lry = ry == 4 ? 2 : ry == 2 ? 1 : 0;
-        const int shift = 7 - lrx;                            // the plane tile is 128 / rx samples wide: a power of two
+        const int sh = lrx + lry;
         uint16_t *dst = tile + first[p];
-        const int nsamples = first[p + 1] - first[p];
-        for (int local = t; local < nsamples; local += kGThreads) {
-            const int ly = local >> shift, lx = local & ((1 << shift) - 1);
-            const uint16_t *box = raw + (ly * ry) * RP + (lx * rx) * COUNT + p;
-            uint32_t sum = 0;
-            for (int dy = 0; dy < ry; ++dy)                   // (wave-uniform trip counts)
-                for (int dx = 0; dx < rx; ++dx) sum += box[dy * RP + dx * COUNT];
-            dst[local] = (uint16_t)(sum >> (lrx + lry));
+        const int ngroups = 16 * th[p];                       // sixteen groups of eight pixels per plane-tile row
+        for (int g = t; g < ngroups; g += kGThreads) {
+            const int ly = g >> 4, gx = g & 15;
+            const uint16_t *box = raw + (ly * ry) * RP + (8 * gx) * COUNT;
+            uint32_t sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // per pixel column, down the box
+            for (int dy = 0; dy < ry; ++dy) {                 // (wave-uniform trip count)
+                uint32_t d[4 * COUNT];
+#pragma unroll
+                for (int i = 0; i < COUNT; ++i) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(box + dy * RP)[i];
+                    d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+                }
+#pragma unroll
+                for (int px = 0; px < 8; ++px) {
+                    const int e = px * COUNT + p;
+                    sum[px] += (e & 1) ? d[e >> 1] >> 16 : d[e >> 1] & 0xffffu;
+                }
+            }
+            uint16_t *out = dst + ly * tw[p];
+            if (rx == 1) {                                    // (wave-uniform)
+                uint4 o;
+                o.x = (sum[0] >> sh) | ((sum[1] >> sh) << 16); o.y = (sum[2] >> sh) | ((sum[3] >> sh) << 16);
+                o.z = (sum[4] >> sh) | ((sum[5] >> sh) << 16); o.w = (sum[6] >> sh) | ((sum[7] >> sh) << 16);
+                *reinterpret_cast<uint4 *>(out + 8 * gx) = o;
+            } else if (rx == 2) {
+                uint2 o;
+                o.x = ((sum[0] + sum[1]) >> sh) | (((sum[2] + sum[3]) >> sh) << 16);
+                o.y = ((sum[4] + sum[5]) >> sh) | (((sum[6] + sum[7]) >> sh) << 16);
+                *reinterpret_cast<uint2 *>(out + 4 * gx) = o;
+            } else {
+                *reinterpret_cast<uint32_t *>(out + 2 * gx) =
+                    ((sum[0] + sum[1] + sum[2] + sum[3]) >> sh) | (((sum[4] + sum[5] + sum[6] + sum[7]) >> sh) << 16);
+            }
         }
     }
+    GP(3)
     __syncthreads();
+    GP(4)
 
     // ---- phase B: one block per work-item; block 4 l + w goes to lane l of wave w, so that a tile with fewer than 256 blocks
     //      (96 for 4:2:0) keeps all four SIMDs busy with a partly filled wave each instead of two with full ones ----
@@ -582,7 +617,9 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     }
     // ---- phase C: blocks out through LDS (the raw tile is no longer needed); chunk c of block t sits at slot c ^ (t & 7) ----
     const uint4 *stage = reinterpret_cast<const uint4 *>(raw);
+    GP(5)
     __syncthreads();
+    GP(6)
     // (plane by plane, like phase A2: no per-lane selects)
 #pragma unroll
     for (int q = 0; q < COUNT; ++q) {
@@ -599,6 +636,15 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
                 *reinterpret_cast<uint4 *>(coef + (size_t)64 * ((size_t)by * ux + bx) + 8 * c) = stage[8 * b + (c ^ (b & 7))];
         }
     }
+    GP(7)
+#ifdef JA_GEN_PHASE
+    {
+        const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+        gp_acc[14] = __builtin_readcyclecounter() - gp_first;
+        if ((threadIdx.x & 63) == 0 && (wid & 15) == 0 && (wid >> 4) < 4096)
+            for (int i = 0; i < 16; ++i) g_gen_phase[(wid >> 4) * 16 + i] = gp_acc[i];
+    }
+#endif
 }
 
 // blocks of a plane along one axis of a tile of `extent` pixels: at most (k_generic_fused derives the exact range per tile)

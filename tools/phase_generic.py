@@ -19,6 +19,13 @@ rect = torch.empty(W * H * 3, dtype=torch.int16, device=dev)
 cp = _lib.ptr_array([t.data_ptr() for t in coef])
 def step():
     assert lib.jpeg_amd_spectral_rectangular(ctx.handle, C.byref(L), cp, q_np.ctypes.data_as(C.c_void_p), 2, 0, rect.data_ptr()) == 0
+back = [torch.empty(64 * a * b, dtype=torch.int16, device=dev) for a, b in units]
+bp = _lib.ptr_array([t.data_ptr() for t in back])
+def step_encode():
+    assert lib.jpeg_amd_rectangular_spectral(ctx.handle, C.byref(L), rect.data_ptr(), q_np.ctypes.data_as(C.c_void_p), 2, bp) == 0
+encode = len(sys.argv) > 1 and sys.argv[1] == "encode"
+if encode:
+    step(); step, names_override = step_encode, True
 for _ in range(4): step()
 torch.cuda.synchronize()
 ctx.timer_begin(); step(); ms = ctx.timer_end()
@@ -28,8 +35,11 @@ assert fn(buf.ctypes.data, buf.size) == 0
 buf = buf[buf[:, 14] > 0]
 names = ["geometry + coefficient loads issued", "tables", "barrier 1", "wait for the coefficients", "IDCT + tile write", "barrier 2",
          "pixel passes: gather + filter", "pixel passes: staging + stores"]
+if encode:
+    names = ["tables + parameters", "A1: rectangular tile -> LDS (incl. the load latency)", "barrier 1", "A2: decomposed() into the plane tiles", "barrier 2",
+             "B: FDCT + quantiser + scatter", "barrier 3", "C: blocks out"]
 tot = buf[:, 14].astype(np.float64)
-print(f"step {ms * 1e3:.1f} us, {len(buf)} waves sampled (every 8th); life mean {tot.mean():.0f} cycles, min {tot.min():.0f}, max {tot.max():.0f}")
+print(f"step {ms * 1e3:.1f} us, {len(buf)} waves sampled (every 8th / 16th); life mean {tot.mean():.0f} cycles, min {tot.min():.0f}, max {tot.max():.0f}")
 for i, n in enumerate(names):
     c = buf[:, i].astype(np.float64)
     print(f"  {n:40s} {c.mean():9.0f} cycles  {100 * c.mean() / tot.mean():5.1f} %   (min {c.min():.0f}, median {np.median(c):.0f}, max {c.max():.0f})")

@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libjpeg_amd.so")
 
 SOURCES = ["kernels_stage.hip", "kernels_fused.hip", "kernels_quad.hip", "kernels_encode.hip", "kernels_generic.hip", "capi.hip", "entropy.cpp", "entropy_encode.cpp"]
-HEADERS = ["dct.hpp", "kernels.hpp", "upsample.hpp", "fused_common.hpp", "worker_pool.hpp"]
+HEADERS = ["dct.hpp", "kernels.hpp", "upsample.hpp", "fused_common.hpp", "quantise.hpp", "worker_pool.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wall", "-Wno-unused-command-line-argument"]
 # Per-source flags.  The transform kernels are compiled WITHOUT the SLP vectoriser: it turns the float arithmetic of the 8-point

@@ -27,6 +27,7 @@
 
 #include "dct.hpp"
 #include "kernels.hpp"
+#include "quantise.hpp"
 
 #include <type_traits>
 
@@ -431,8 +432,8 @@ struct GenEncArgs {
     int tiles_x;
 };
 
-template <int COUNT, int GEH>
-__global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_encode(GenEncArgs a)
+template <int COUNT, int GEH, int NT = kGThreads>
+__global__ __launch_bounds__(NT, (GEH == 64 ? 2 : 4)) void k_generic_encode(GenEncArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint16_t raw[GEW * GEH * COUNT];    // the tile of Rectangular; later the blocks on their way out
     extern __shared__ __attribute__((aligned(16))) uint16_t tile[];                // plane tiles: as many samples as the layout's planes have under a tile
@@ -444,9 +445,23 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     const int t = threadIdx.x, img = blockIdx.y;
     const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
     const int x0 = txi * GEW, y0 = tyi * GEH;
+    // ---- phase A1, first half: a tile inside the image REQUESTS its samples before the tables are built -- the two memory latencies at
+    //      the head of a workgroup, quanta and samples, overlap (tools/phase_generic.py: they were 42 % of a wave's life in a row) ----
+    const uint16_t *rect = a.rect + img * a.rect_stride;
+    constexpr int RP = GEW * COUNT;                         // uint16 per tile row
+    constexpr int NSTEP = GEH * (RP / 8) / NT;              // 16-byte chunks per work-item
+    static_assert(GEH * (RP / 8) % NT == 0, "the tile's chunks divide among the work-items");
+    const bool interior = x0 + GEW <= a.W && y0 + GEH <= a.H;   // (wave-uniform)
+    uint4 pre[NSTEP];
+#pragma unroll
+    for (int k = 0; k < NSTEP; ++k) {
+        const int i = t + k * NT, row = i / (RP / 8), ch = i - row * (RP / 8);
+        pre[k] = make_uint4(0, 0, 0, 0);
+        if (interior) pre[k] = *reinterpret_cast<const uint4 *>(rect + ((size_t)a.W * (y0 + row) + x0) * COUNT + 8 * ch);   // (rows need not be 16-byte aligned)
+    }
     {
-        const int p = t >> 6, e = t & 63;
-        if (p < COUNT) {
+        const int e = t & 63;
+        for (int p = t >> 6; p < COUNT; p += NT / 64) {
             const float qv = modulate_entry(e & 7, e >> 3, 8.0f, a.quanta[img * a.quanta_stride + 64 * a.pl[p].qi + zigzag_of(e & 7, e >> 3)]);
             sq[p][e] = qv;
             sr[p][e] = 1.0f / qv;          // IEEE division: RN(1 / q)
@@ -468,9 +483,13 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     GP(0)
     // ---- phase A1: the tile of Rectangular as it lies in memory -> LDS, 16 bytes per work-item and step; a sample beyond the
     //      image is the nearest one inside (encode.swift:415-417: the box clamps its indices), fetched one at a time ----
-    const uint16_t *rect = a.rect + img * a.rect_stride;
-    constexpr int RP = GEW * COUNT;                         // uint16 per tile row
-    for (int i = t; i < GEH * (RP / 8); i += kGThreads) {
+#pragma unroll
+    for (int k = 0; k < NSTEP; ++k) {
+        const int i = t + k * NT, row = i / (RP / 8), ch = i - row * (RP / 8);
+        if (interior) *reinterpret_cast<uint4 *>(raw + row * RP + 8 * ch) = pre[k];
+    }
+    if (!interior)
+    for (int i = t; i < GEH * (RP / 8); i += NT) {
         const int row = i / (RP / 8), ch = i - row * (RP / 8);
         const int yy = min(y0 + row, a.H - 1);
         const uint16_t *src = rect + ((size_t)a.W * yy + x0) * COUNT;
@@ -508,7 +527,7 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
         const int sh = lrx + lry;
         uint16_t *dst = tile + first[p];
         const int ngroups = 16 * th[p];                       // sixteen groups of eight pixels per plane-tile row
-        for (int g = t; g < ngroups; g += kGThreads) {
+        for (int g = t; g < ngroups; g += NT) {
             const int ly = g >> 4, gx = g & 15;
             const uint16_t *box = raw + (ly * ry) * RP + (8 * gx) * COUNT;
             uint32_t sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // per pixel column, down the box
@@ -550,7 +569,7 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
     //      (96 for 4:2:0) keeps all four SIMDs busy with a partly filled wave each instead of two with full ones ----
     bool have = false;
     int p = 0, gbx = 0, gby = 0;
-    const int blk = fb[COUNT] > 160 ? t : 4 * (t & 63) + (t >> 6);   // (three or four full waves: as they come)
+    const int blk = fb[COUNT] > 5 * NT / 8 ? t : (NT / 64) * (t & 63) + (t >> 6);   // (nearly full waves: as they come)
     if (blk < fb[COUNT]) {
 #pragma unroll
         for (int q = 1; q < COUNT; ++q) p += blk >= fb[q];
@@ -581,7 +600,8 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
             }
             // the coefficients go straight to the staging area (the raw tile is no longer needed: every work-item is past the
             // barrier behind phase A2): int16 at its zigzag position z of block b, 16-byte chunk z / 8 at slot (z / 8) ^ (b & 7)
-            uint16_t *mine = raw + 64 * blk;
+            uint32_t *mine = reinterpret_cast<uint32_t *>(raw + 64 * blk);
+            float zf[64];   // by zigzag index: y1 + copysign(pred(1/2), y1), whose truncation is the rounded coefficient
             // (opaque empty statements pin the program order: left alone, LLVM hoists the table reads of all eight columns over the
             // arithmetic and spills -- kernels_encode.hip's fdct_quantise met the same)
 #pragma unroll
@@ -605,12 +625,12 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
                     const float y0 = res[h] * rr;
                     const float e1 = __builtin_fmaf(-y0, qq, res[h]);
                     const float y1 = __builtin_fmaf(e1, rr, y0);
-                    const float hf = __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(0x7fffffffu, __builtin_bit_cast(uint32_t, 0.49999997f),
-                                                                                          __builtin_bit_cast(uint32_t, y1), 0xca));   // copysign(pred(1/2), y1)
-                    const int32_t c = (int32_t)(y1 + hf);
-                    const int z = zigzag_of(k, h);
-                    mine[8 * ((z >> 3) ^ (blk & 7)) + (z & 7)] = (uint16_t)c;
+                    zf[zigzag_of(k, h)] = y1 + half_toward(y1);
                 }
+                // a pair of zigzag neighbours is converted, packed (two conversions, the second into the upper half: quantise.hpp) and
+                // written as one dword as soon as the later of its two columns is done; the int16 the reference stores is the low half
+                // of the integer either way
+                store_ready_pairs(zf, mine, blk & 7, k, std::make_integer_sequence<int, 32>{});
                 __builtin_amdgcn_sched_barrier(0);   // one column at a time: eight divisions in flight are register pressure enough
             }
         }
@@ -628,7 +648,7 @@ __global__ __launch_bounds__(kGThreads, (GEH == 64 ? 2 : 4)) void k_generic_enco
         int16_t *coef = a.pl[q].coef + img * a.pl[q].stride;
         const int bx0 = x0 / (8 * rx), by0 = y0 / (8 * ry);
         (void)nbx;
-        for (int j = t; j < 8 * (fb[q + 1] - fb[q]); j += kGThreads) {
+        for (int j = t; j < 8 * (fb[q + 1] - fb[q]); j += NT) {
             const int local = j >> 3, c = j & 7, b = fb[q] + local;
             const int lby = local >> shift, lbx = local & ((1 << shift) - 1);
             const int bx = bx0 + lbx, by = by0 + lby;
@@ -754,8 +774,12 @@ hipError_t launch_generic_encode(hipStream_t stream, int n_images, const jpeg_am
     }
     if (n_images == 0 || need_x == 0 || need_y == 0) return hipSuccess;
     // tile height: 32 rows.  64 rows would fill the workgroup better (4:2:0: 192 blocks instead of 96 under 32 rows)
-    int blocks64 = 0;
-    for (int p = 0; p < L.nplanes; ++p) blocks64 += (GEW / (8 * a.pl[p].rx)) * (64 / (8 * a.pl[p].ry));
+    int blocks64 = 0, blocks32 = 0;
+    for (int p = 0; p < L.nplanes; ++p) {
+        blocks64 += (GEW / (8 * a.pl[p].rx)) * (64 / (8 * a.pl[p].ry));
+        blocks32 += (GEW / (8 * a.pl[p].rx)) * (32 / (8 * a.pl[p].ry));
+    }
+    (void)blocks32;
     // (measured: 64-row tiles are SLOWER -- 8192 x 8192 12-bit 4:2:0 472 against 403 us, 4:2:2 923 against 490 -- although they fill
     // the workgroup's lanes: fewer, larger workgroups hide less of each other's barriers.  JA_X_GENERIC_ENCODE_64 builds them.)
 #ifdef JA_X_GENERIC_ENCODE_64
@@ -772,7 +796,12 @@ hipError_t launch_generic_encode(hipStream_t stream, int n_images, const jpeg_am
 #define JA_GE(C_) do { if (geh == 64) hipLaunchKernelGGL((k_generic_encode<C_, 64>), grid, dim3(kGThreads), tile_bytes, stream, a); \
                        else hipLaunchKernelGGL((k_generic_encode<C_, 32>), grid, dim3(kGThreads), tile_bytes, stream, a); } while (0)
 #else
+#ifdef JA_X_GENC_NT
+#define JA_GE(C_) do { if (blocks32 <= JA_X_GENC_NT) hipLaunchKernelGGL((k_generic_encode<C_, 32, JA_X_GENC_NT>), grid, dim3(JA_X_GENC_NT), tile_bytes, stream, a); \
+                       else hipLaunchKernelGGL((k_generic_encode<C_, 32>), grid, dim3(kGThreads), tile_bytes, stream, a); } while (0)
+#else
 #define JA_GE(C_) hipLaunchKernelGGL((k_generic_encode<C_, 32>), grid, dim3(kGThreads), tile_bytes, stream, a)
+#endif
 #endif
     switch (L.nplanes) {
     case 1: JA_GE(1); break;

@@ -565,11 +565,16 @@ __global__ __launch_bounds__(NT, (GEH == 64 ? 2 : 4)) void k_generic_encode(GenE
     __syncthreads();
     GP(4)
 
-    // ---- phase B: one block per work-item; block 4 l + w goes to lane l of wave w, so that a tile with fewer than 256 blocks
-    //      (96 for 4:2:0) keeps all four SIMDs busy with a partly filled wave each instead of two with full ones ----
+    // ---- phase B: one block per work-item; a tile with fewer than 256 blocks (96 for 4:2:0) is dealt to ALL waves, a quarter each, so
+    //      that the four SIMDs are busy with a partly filled wave each instead of two with full ones ----
     bool have = false;
     int p = 0, gbx = 0, gby = 0;
-    const int blk = fb[COUNT] > 5 * NT / 8 ? t : (NT / 64) * (t & 63) + (t >> 6);   // (nearly full waves: as they come)
+    // (nearly full waves: as they come; else every wave a RUN of consecutive blocks, the same number each -- neighbouring lanes then
+    // read neighbouring 16-byte pieces of a tile row and write blocks 128 bytes apart under the chunk swizzle: block 4 l + w in lane l
+    // of wave w, round 5's cut, put every fourth block of a row into a wave and its writes twelve to a bank:
+    // SQ_LDS_BANK_CONFLICT 55 M cycles against 16 M of LDS work, profiles/r06_pmc_generic.txt)
+    const int per_wave = (fb[COUNT] + NT / 64 - 1) / (NT / 64);
+    const int blk = fb[COUNT] > 5 * NT / 8 ? t : ((t & 63) < per_wave ? per_wave * (t >> 6) + (t & 63) : fb[COUNT]);
     if (blk < fb[COUNT]) {
 #pragma unroll
         for (int q = 1; q < COUNT; ++q) p += blk >= fb[q];

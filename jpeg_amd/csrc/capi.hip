@@ -585,7 +585,7 @@ int jpeg_amd_spectral_rectangular_batch(jpeg_amd_ctx *ctx, const jpeg_amd_layout
     for (int p = 0; p < L->nplanes; ++p) { cs.ptr[p] = d_coef[p]; cs.stride[p] = coef_stride[p]; }
     if (generic_fused_supported(*L)) {
         JA_HIP(ctx, launch_generic_fused(ctx->stream, n_images, *L, cs, QuantaRef{d_quanta, quanta_stride}, cosited != 0,
-                                         d_rect, rect_stride));
+                                         ctx->d_walk ? ctx->d_walk + 16 : nullptr, d_rect, rect_stride));   // (dword 16: the 4:2:0 walk owns dword 0)
         return JPEG_AMD_OK;
     }
     // staged path (any factors): IDCT every plane into uint16 scratch planes, then upsample + interleave

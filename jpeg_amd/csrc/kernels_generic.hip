@@ -26,6 +26,7 @@
 #pragma clang fp contract(off)
 
 #include "dct.hpp"
+#include "fused_common.hpp"
 #include "kernels.hpp"
 #include "quantise.hpp"
 
@@ -62,7 +63,8 @@ struct GenArgs {
     float level, limit;   // decode.swift:4110-4113
     uint16_t *out;
     size_t out_stride;    // elements between images
-    int tiles_x;
+    int tiles_x, tiles_per_image, total_tiles;   // the call's tiles: image-major, then row-major
+    uint32_t *tickets;    // the tiles beyond the first round are DRAWN from this counter (zeroed in front of the launch); nullptr: planned
 };
 
 // Float.rounded() (to nearest, ties away from zero: decode.swift:4264) of a NON-NEGATIVE float, exactly and without a select:
@@ -89,7 +91,7 @@ __device__ __forceinline__ int div_trunc_small(int n, int c, int log2c, uint32_t
 // phase of its tile), JA_X_GEN_NOLOAD / JA_X_GEN_NOSTORE (the tile without its coefficient loads / its global stores).
 #ifdef JA_GEN_PHASE
 __device__ unsigned long long g_gen_phase[4096 * 16];
-#define GP_DECL unsigned long long gp_acc[16] = {}; unsigned long long gp_prev = __builtin_readcyclecounter(); const unsigned long long gp_first = gp_prev;
+#define GP_DECL unsigned long long gp_acc[16] = {}; unsigned long long gp_prev = __builtin_readcyclecounter(); const unsigned long long gp_first = gp_prev, gp_real = __builtin_amdgcn_s_memrealtime();
 #define GP(i) { const unsigned long long n_ = __builtin_readcyclecounter(); gp_acc[i] += n_ - gp_prev; gp_prev = n_; }
 #else
 #define GP_DECL
@@ -101,8 +103,8 @@ __device__ unsigned long long g_gen_phase[4096 * 16];
 // floats arrive as kernel arguments: 4:4:4 16-bit 188 -> 172 us, 4:2:2 12-bit 252 -> 230, 4:1:1 233 -> 222 (8192 x 8192,
 // profiles/r06_generic_four_waves.txt).  Four planes: three (42-50 KiB), staged four rows at a time.
 template <int COUNT> constexpr int generic_waves_per_simd() { return COUNT == 4 ? 3 : 4; }
-template <int TH, int COUNT>
-__global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void k_generic_fused(GenArgs a)
+template <int TH, int COUNT, bool WALK>
+__global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void k_generic_fused(GenArgs a_)
 {
     constexpr int SROWS = COUNT == 4 ? 4 : 2;   // pixel rows a wave stages at a time
     GP_DECL
@@ -111,8 +113,52 @@ __global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void 
     __shared__ float tt[JPEG_AMD_MAX_PLANES][2][12];                          // t = clamp(Float(f) / Float(c)), f = -3 .. 8 (at index f + 3)
     __shared__ __attribute__((aligned(16))) uint32_t ostage[kGThreads / 64][SROWS * 64 * COUNT];   // per wave: SROWS rows x 128 px x COUNT samples
 
-    const int t = threadIdx.x, img = blockIdx.y;
-    const int tyi = blockIdx.x / a.tiles_x, txi = blockIdx.x - tyi * a.tiles_x;
+    // WALK (round 6): the workgroups of a launch are RESIDENT and walk the call's tiles.  With a workgroup per tile only 2.4 of the
+    // four workgroups a CU holds were resident on average (tools/phase_generic.py: 8 192 workgroups x 16.7 us of life in a step of 222 us):
+    // the slot of a finished workgroup stays empty for as long as a workgroup lives.  The walk is written so that a trip compiles like
+    // the one-tile kernel: the kernel-argument pointer and the work-item id are made opaque at the top of every trip, so nothing that
+    // depends on them -- a hundred wave-uniform scalars of four planes -- is hoisted out of the walk into registers the kernel does not
+    // have (the first attempts: 303-381 us against 221, tools/exp_patches/r06_generic_decode_tile_walk*.diff).
+    typedef const __attribute__((address_space(4))) GenArgs KArgs;
+    const int total_tiles = a_.total_tiles;
+    // The tiles beyond a workgroup's first are DRAWN from a counter (a.tickets): tiles differ -- those of the image's first and last
+    // column, whose edge pixels take the literal filter, cost four times the others, and a plain stride hands a workgroup the SAME
+    // tile column on every trip whenever the grid is a multiple of the tiles per row: eight edge tiles in a row made 32 workgroups the
+    // last to leave by 90 us (tools/timeline_generic.py) --, XCDs differ in clock, and with tickets whoever is free takes the next
+    // tile.  Work-item 0 draws the ticket of the NEXT trip at the top of a trip and publishes it in front of the trip's second
+    // barrier.  Without a counter (a call of at most one round) the walk is the plain stride.
+    __shared__ int s_next[2];
+    // !WALK: a workgroup per tile (grid: tiles x images), one trip, nothing drawn -- the layouts the walk does not pay for (see
+    // launch_generic_fused) keep the straight-line kernel: the same body inside a loop of one trip costs them 5-10 %.
+    int tile_id = WALK ? (int)blockIdx.x : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    if (tile_id >= total_tiles) return;
+#pragma unroll 1
+    for (int trip = 0;; ++trip) {
+#ifndef JA_X_GEN_NOPRIO
+    if constexpr (WALK)
+    // A SIMD issues its OLDEST ready wave first: of the four resident workgroups of a CU the youngest would fall behind trip after trip
+    // and finish long after the others (without this: mean life of a workgroup 147 us, the step 291).  As in the strip walks, a wave
+    // with more tiles left runs at a higher priority, so all of them leave within a tile of each other.
+    {
+        const int left = (total_tiles - 1 - tile_id) / (int)gridDim.x;   // rounds after this tile's
+        if (left >= 3) __builtin_amdgcn_s_setprio(3);
+        else if (left == 2) __builtin_amdgcn_s_setprio(2);
+        else if (left == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
+    KArgs *ap = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    if constexpr (WALK) asm volatile("" : "+s"(ap));
+    // (WALK: the arguments through the opaque pointer; else the by-value parameter itself)
+    const auto *args_ptr = [&]() { if constexpr (WALK) return ap; else return static_cast<const GenArgs *>(&a_); }();
+    const auto &a = *args_ptr;
+    int t = threadIdx.x;
+    if constexpr (WALK) asm volatile("" : "+v"(t));
+    uint32_t drawn = 0;
+    if constexpr (WALK)
+        if (a.tickets != nullptr && t == 0) drawn = __hip_atomic_fetch_add(a.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int img = WALK ? tile_id / a.tiles_per_image : (int)blockIdx.y, tin = WALK ? tile_id - img * a.tiles_per_image : (int)blockIdx.x;
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
     const int x0 = txi * GTW, y0 = tyi * TH;
 
     // ---- the tile's blocks, plane by plane (wave-uniform scalars) ----
@@ -120,7 +166,7 @@ __global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void 
     first[0] = 0;
 #pragma unroll
     for (int p = 0; p < COUNT; ++p) {
-        const GenPlane &P = a.pl[p];
+        const auto &P = a.pl[p];
         int nby;
         if (P.direct || P.fastx) {
             const bool hx = !P.direct && P.rx == 2;
@@ -146,6 +192,10 @@ __global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void 
     //      (round 6; the waves of a tile spent 39 % of their cycles in s_waitcnt / the barriers: profiles/r06_pmc_generic.txt) ----
     bool have = false;
     uint32_t w[32];
+    if constexpr (WALK) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) w[i] = 0;   // (defined on every path of every trip: an undefined value would be carried around the walk -- and spilled)
+    }
     int p = 0, f0 = 0, nx = 1, lbx = 0, lby = 0;
     if (t < first[COUNT]) {
 #pragma unroll
@@ -219,6 +269,8 @@ __global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void 
         }
     }
     GP(4)
+    if constexpr (WALK)
+        if (t == 0) s_next[(trip + 1) & 1] = a.tickets != nullptr ? (int)gridDim.x + (int)drawn : tile_id + (int)gridDim.x;
     __syncthreads();
     GP(5)
 
@@ -246,7 +298,7 @@ __global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s[i] = (d[i >> 1] >> (16 * (i & 1))) & 0xffffu;
             } else {
-                const GenPlane &P = a.pl[p];
+                const auto &P = a.pl[p];
                 const int pw = 8 * P.ux, ph = 8 * P.uy;
                 const int cols = pitch;
                 // the row's vertical position: decode.swift:4240-4251 for y
@@ -384,10 +436,22 @@ __global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void 
         }
         GP(7)
     }
+    if constexpr (!WALK) break;
+    tile_id = s_next[(trip + 1) & 1];
+    if (tile_id >= total_tiles) break;   // (wave-uniform)
+    }   // the walk.  (No barrier between trips: the next trip's first LDS writes -- the tables -- touch nothing phase B reads but the
+        // weights tt, which are the same for every tile of a call; its tile writes come behind its own first barrier.)
 #ifdef JA_GEN_PHASE
     {
         const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
         gp_acc[14] = __builtin_readcyclecounter() - gp_first;
+        gp_acc[15] = __builtin_amdgcn_s_memrealtime() - gp_real;   // ticks of the constant 100 MHz counter
+        {
+            unsigned hw_, xcc_;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+            gp_acc[12] = gp_real; gp_acc[13] = ((unsigned long long)(xcc_ & 15u) << 32) | hw_;
+        }
         if ((threadIdx.x & 63) == 0 && (wid & 7) == 0 && (wid >> 3) < 4096)
             for (int i = 0; i < 16; ++i) g_gen_phase[(wid >> 3) * 16 + i] = gp_acc[i];
     }
@@ -705,7 +769,7 @@ bool generic_fused_supported(const jpeg_amd_layout &L)
 }
 
 hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd_layout &L, const PlaneSet &coef, QuantaRef q,
-                                bool cosited, uint16_t *d_rect, size_t rect_stride)
+                                bool cosited, uint32_t *d_walk_counter, uint16_t *d_rect, size_t rect_stride)
 {
     GenArgs a{};
     a.count = L.nplanes; a.W = L.width; a.H = L.height;
@@ -736,8 +800,34 @@ hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd
     if (n_images == 0) return hipSuccess;
     const int th = tile_blocks(L, 64) <= kGThreads ? 64 : 32;
     a.tiles_x = (L.width + GTW - 1) / GTW;
-    const dim3 grid(a.tiles_x * ((L.height + th - 1) / th), n_images);
-#define JA_G(TH_, C_) hipLaunchKernelGGL((k_generic_fused<TH_, C_>), grid, dim3(kGThreads), 0, stream, a)
+    a.tiles_per_image = a.tiles_x * ((L.height + th - 1) / th);
+    if ((long long)a.tiles_per_image * n_images > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.total_tiles = a.tiles_per_image * n_images;
+    // The walk (resident workgroups, tickets) or a workgroup per tile?  Measured on nine layouts at 8192 x 8192 (profiles/r06_generic_walk.txt):
+    // the walk wins where a tile is long and held up by its own latencies -- 64-row tiles whose subsampled planes all take the exact
+    // filter: 4:2:0 centred or cosited, 213 -> 190 us at 12 bits, 197 -> 177 at 8 -- and loses where the kernel is close to a
+    // throughput limit and the dispatcher's natural stagger of the workgroups is worth more than their residency (4:4:4 16-bit at
+    // 4.7 TB/s: 172 -> 228 us; the layouts on the literal filter, 4:1:1, 4:1:0, thirds: 220 -> 240).  Those keep a workgroup per tile:
+    // the same kernel with a grid of all tiles makes one trip and draws nothing.
+    bool subsampled = false, all_exact = true;
+    for (int p = 0; p < L.nplanes; ++p)
+        if (!a.pl[p].direct) { subsampled = true; all_exact = all_exact && a.pl[p].fastx && a.pl[p].fasty && a.pl[p].lgy >= 0; }
+    const bool walk = th == 64 && subsampled && all_exact;
+#define JA_GK(K_)                                                                                                       \
+    {                                                                                                                   \
+        const int cap = resident_workgroups_of<K_>(3);                                                                  \
+        a.tickets = a.total_tiles > cap ? d_walk_counter : nullptr;                                                     \
+        if (a.tickets) {   /* (a 2 us node in front of a call of several rounds) */                                      \
+            const hipError_t m_ = hipMemsetAsync(a.tickets, 0, sizeof(uint32_t), stream);                               \
+            if (m_ != hipSuccess) return m_;                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL(K_, dim3(a.total_tiles < cap ? a.total_tiles : cap), dim3(kGThreads), 0, stream, a);          \
+    }
+#define JA_G(TH_, C_)                                                                                                   \
+    {                                                                                                                   \
+        if (TH_ == 64 && walk) JA_GK((k_generic_fused<64, C_, true>))                                                   \
+        else hipLaunchKernelGGL((k_generic_fused<TH_, C_, false>), dim3(a.tiles_per_image, n_images), dim3(kGThreads), 0, stream, a); \
+    }
 #define JA_GC(TH_)                               \
     switch (L.nplanes) {                         \
     case 1: JA_G(TH_, 1); break;                 \
@@ -748,6 +838,7 @@ hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd
     if (th == 64) { JA_GC(64) } else { JA_GC(32) }
 #undef JA_GC
 #undef JA_G
+#undef JA_GK
     return hipGetLastError();
 }
 

@@ -96,7 +96,8 @@ hipError_t launch_quad_decode(hipStream_t stream, int n_images, const jpeg_amd_l
 // Spectral -> Rectangular (uint16 [H][W][count]) in one launch for the JPEG.Format plug-in path (kernels_generic.hip): any
 // precision 1 .. 16, 1 .. 4 planes, centred or cosited, every plane at the image's scale or at half of it per axis.
 bool       generic_fused_supported(const jpeg_amd_layout &layout);
-// `d_walk_counter`: a device dword the caller keeps for the stream (calls of several rounds draw their tiles through it; nullptr: planned)
+// `d_walk_counter`: TWO device dwords the caller keeps for the stream, zero when handed over (calls of several rounds draw their tiles
+// through them and leave them zero; nullptr: planned)
 hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd_layout &layout, const PlaneSet &coef,
                                 QuantaRef q, bool cosited, uint32_t *d_walk_counter, uint16_t *d_rect, size_t rect_stride);
 

@@ -64,7 +64,8 @@ struct GenArgs {
     uint16_t *out;
     size_t out_stride;    // elements between images
     int tiles_x, tiles_per_image, total_tiles;   // the call's tiles: image-major, then row-major
-    uint32_t *tickets;    // the tiles beyond the first round are DRAWN from this counter (zeroed in front of the launch); nullptr: planned
+    uint32_t *tickets;    // the tiles beyond the first round are DRAWN from this counter: two dwords, zero between calls (the last workgroup
+                          // to leave resets them); nullptr: planned
 };
 
 // Float.rounded() (to nearest, ties away from zero: decode.swift:4264) of a NON-NEGATIVE float, exactly and without a select:
@@ -158,7 +159,14 @@ __global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void 
     if constexpr (WALK)
         if (a.tickets != nullptr && t == 0) drawn = __hip_atomic_fetch_add(a.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int img = WALK ? tile_id / a.tiles_per_image : (int)blockIdx.y, tin = WALK ? tile_id - img * a.tiles_per_image : (int)blockIdx.x;
-    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    // WALK: the tiles of an image are taken in the order "first and last column, then the rest": the column tiles are the expensive
+    // ones (their edge pixels take the literal filter: +12 us each), and drawn last they would be the call's tail
+    int tyi, txi;
+    if (WALK && a.tiles_x >= 3) {
+        const int tiles_y = a.tiles_per_image / a.tiles_x, inner = a.tiles_x - 2;
+        if (tin < 2 * tiles_y) { tyi = tin >> 1; txi = (tin & 1) ? a.tiles_x - 1 : 0; }
+        else { const int r = tin - 2 * tiles_y; tyi = r / inner; txi = 1 + r - tyi * inner; }
+    } else { tyi = tin / a.tiles_x; txi = tin - tyi * a.tiles_x; }
     const int x0 = txi * GTW, y0 = tyi * TH;
 
     // ---- the tile's blocks, plane by plane (wave-uniform scalars) ----
@@ -438,7 +446,19 @@ __global__ __launch_bounds__(kGThreads, (generic_waves_per_simd<COUNT>())) void 
     }
     if constexpr (!WALK) break;
     tile_id = s_next[(trip + 1) & 1];
-    if (tile_id >= total_tiles) break;   // (wave-uniform)
+    if (tile_id < total_tiles) continue;   // (wave-uniform)
+    if constexpr (WALK) {
+        // the last workgroup to leave puts the counter back to zero for the next call (tickets[1] counts the leavers): no memset node
+        // in front of the launch (2-3 us and a gap in the stream)
+        if (a.tickets != nullptr && t == 0) {
+            const uint32_t left_before = __hip_atomic_fetch_add(a.tickets + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (left_before == gridDim.x - 1) {
+                __hip_atomic_store(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        break;
+    }
     }   // the walk.  (No barrier between trips: the next trip's first LDS writes -- the tables -- touch nothing phase B reads but the
         // weights tt, which are the same for every tile of a call; its tile writes come behind its own first barrier.)
 #ifdef JA_GEN_PHASE
@@ -816,11 +836,7 @@ hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd
 #define JA_GK(K_)                                                                                                       \
     {                                                                                                                   \
         const int cap = resident_workgroups_of<K_>(3);                                                                  \
-        a.tickets = a.total_tiles > cap ? d_walk_counter : nullptr;                                                     \
-        if (a.tickets) {   /* (a 2 us node in front of a call of several rounds) */                                      \
-            const hipError_t m_ = hipMemsetAsync(a.tickets, 0, sizeof(uint32_t), stream);                               \
-            if (m_ != hipSuccess) return m_;                                                                            \
-        }                                                                                                               \
+        a.tickets = a.total_tiles > cap ? d_walk_counter : nullptr;   /* (two dwords, zero between calls: the kernel resets them) */ \
         hipLaunchKernelGGL(K_, dim3(a.total_tiles < cap ? a.total_tiles : cap), dim3(kGThreads), 0, stream, a);          \
     }
 #define JA_G(TH_, C_)                                                                                                   \

@@ -203,6 +203,11 @@ __device__ __forceinline__ void wave_store_blocks_halves(const uint32_t (&w)[32]
 // would not fill the chip (a 4096 x 4096 frame is 512 tiles of 16 rows: two waves per SIMD, each of them bound by
 // its own instruction latency).
 // POOLI: 4:2:0 only -- the 2 x 2 box filter in the integer domain (launches of several rounds; see POOL_INT below).
+#ifdef JA_ENC_TIMELINE
+}  // namespace
+__device__ unsigned long long g_enc_timeline[2 * 32768];
+namespace {
+#endif
 template <int SX, int SY, bool RGB, bool CHROMA, bool FASTIN, int TY = ETY, bool POOLI = false>
 // 4:2:2 / 4:4:0 (chroma pooled per half tile) are built for TWO waves per SIMD: at three (168 VGPRs) the register allocator
 // spills 9-19 registers of the FAST variants, and a spill reload waits with vmcnt(0) for every store in flight -- 4:4:0 at
@@ -240,6 +245,9 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? ((CHROMA && SX == 1 && SY == 1
         if constexpr (HALFSTAGE) wave_store_blocks_halves(w, stage, lane, plane, block);
         else wave_store_blocks(w, stage, lane, plane, block);
     };
+#ifdef JA_ENC_TIMELINE   // development aid (tools/timeline_encode.py): start and end of every workgroup on the constant 100 MHz counter
+    const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const int img = blockIdx.y;
     // Wave priorities: everything up to the barrier in front of the chroma blocks runs at the top priority, the chroma blocks
     // one below.  Measured, not derived (profiles/r02_ab_encode_priority.txt): 4096 x 4096 4:2:0 23.1 against 25.0 us on the
@@ -520,10 +528,24 @@ __global__ __launch_bounds__(kThreads, (TY == 8 ? ((CHROMA && SX == 1 && SY == 1
 #endif
         chroma_blocks(0);
     }
-
+#ifdef JA_ENC_TIMELINE
+    {
+        const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+        if (threadIdx.x == 0 && wg < 32768) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            g_enc_timeline[2 * wg] = tl_start; g_enc_timeline[2 * wg + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+#endif
 }
 
 }  // namespace
+#ifdef JA_ENC_TIMELINE
+extern "C" int jpeg_amd_debug_encode_timeline(unsigned long long *h_out, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(h_out, HIP_SYMBOL(jpeg_amd::g_enc_timeline), n * sizeof(unsigned long long));
+}
+#endif
 
 // development switch (-DJA_X_ENC_TY=8 / 16, tools/build_exp.sh): forces the tile height of the grey / 4:2:0 encode kernels
 static int encode_ty_override()

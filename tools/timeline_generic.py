@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Start, end and placement (XCC, SE, CU) of every sampled workgroup of k_generic_fused on one 8192 x 8192 4:2:0 12-bit image: who is resident
+when, who leaves last and in which phase it lost its time (needs a -DJA_GEN_PHASE build):
+    tools/build_exp.sh gphase -DJA_GEN_PHASE; JPEG_AMD_LIBRARY=tools/exp/libjpeg_amd_gphase.so python tools/timeline_generic.py"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import jpeg_amd as J
 from jpeg_amd import _lib, synth

@@ -566,6 +566,47 @@ def test_generic_fused_batch_strides(J, ctx):
         assert (got[i] == want.reshape(-1)).all(), i
 
 
+@pytest.mark.parametrize("cosited", [False, True])
+def test_generic_fused_tile_walk_over_several_rounds_and_images(J, ctx, cosited):
+    """The resident, ticket-drawn tile walk of k_generic_fused (4:2:0 layouts): five 12-bit images of 2000 x 1490 with their own
+    tables are 5 x 16 x 24 = 1 920 tiles -- more than the 1 024 workgroups resident at once, so tiles are drawn from the counter, across
+    image boundaries (the tables change under a resident workgroup), with edge tiles in both directions; twice in a row (the last
+    workgroup to leave must have put the counter back).  Against the oracle on one image and against each image's own single call."""
+    import ctypes as C
+    import torch
+    from jpeg_amd import _lib
+    rng = np.random.default_rng(4100 + cosited)
+    size, n = (2000, 1490), 5
+    layout = J.Layout(("custom", 12, 3), {1: J.Component((2, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    units = layout.units(size)
+    L = layout.c_layout(size, units, [0, 1, 1])
+    host = [[np.clip(rng.laplace(0, 300, (uy, ux, 64)), -8000, 8000).astype(np.int16) for ux, uy in units] for _ in range(n)]
+    tables = rng.integers(1, 30, (n, 2, 64)).astype(np.uint16)
+    d_planes = [torch.from_numpy(np.stack([host[i][p] for i in range(n)])).to(ctx.torch_device) for p in range(3)]
+    d_q = torch.from_numpy(tables.view(np.int16)).to(ctx.torch_device)
+    npx = size[0] * size[1] * 3
+    lib = _lib.lib()
+    outs = []
+    for _ in range(2):
+        out = torch.zeros((n, npx), dtype=torch.int16, device=ctx.torch_device)
+        st = lib.jpeg_amd_spectral_rectangular_batch(ctx.handle, C.byref(L), n, _lib.ptr_array([p.data_ptr() for p in d_planes]),
+                                                     _lib.size_array([64 * a * b for a, b in units]), d_q.data_ptr(), 128, 2, int(cosited),
+                                                     out.data_ptr(), npx)
+        assert st == 0
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    single = torch.zeros(npx, dtype=torch.int16, device=ctx.torch_device)
+    for i in range(n):
+        st = lib.jpeg_amd_spectral_rectangular_batch(ctx.handle, C.byref(L), 1, _lib.ptr_array([p[i].data_ptr() for p in d_planes]),
+                                                     _lib.size_array([0, 0, 0]), d_q[i].data_ptr(), 0, 2, int(cosited), single.data_ptr(), 0)
+        assert st == 0
+        assert torch.equal(single, outs[0][i]), i
+    i = 3
+    want_p = [O.idct_plane(host[i][p], tables[i][min(p, 1)], 12) for p in range(3)]
+    want = O.interleave(want_p, [(2, 2), (1, 1), (1, 1)], (2, 2), size, cosited=cosited)
+    assert (outs[0][i].cpu().numpy().view(np.uint16) == want.reshape(-1)).all()
+
+
 @pytest.mark.parametrize("case", range(len(GENERIC_FUSED)))
 def test_generic_fused_encode_matches_oracle_and_staged(J, ctx, case):
     """jpeg_amd_rectangular_spectral == decomposed().fdct(quanta:) (encode.swift:389-425, 199-248) for custom formats, one launch:

@@ -750,6 +750,7 @@ __global__ __launch_bounds__(NT, (GEH == 64 ? 2 : 4)) void k_generic_encode(GenE
     {
         const unsigned wid = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
         gp_acc[14] = __builtin_readcyclecounter() - gp_first;
+        gp_acc[15] = __builtin_amdgcn_s_memrealtime() - gp_real;
         if ((threadIdx.x & 63) == 0 && (wid & 15) == 0 && (wid >> 4) < 4096)
             for (int i = 0; i < 16; ++i) g_gen_phase[(wid >> 4) * 16 + i] = gp_acc[i];
     }

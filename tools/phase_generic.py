@@ -39,7 +39,13 @@ if encode:
     names = ["tables + parameters", "A1: rectangular tile -> LDS (incl. the load latency)", "barrier 1", "A2: decomposed() into the plane tiles", "barrier 2",
              "B: FDCT + quantiser + scatter", "barrier 3", "C: blocks out"]
 tot = buf[:, 14].astype(np.float64)
-print(f"step {ms * 1e3:.1f} us, {len(buf)} waves sampled (every 8th / 16th); life mean {tot.mean():.0f} cycles, min {tot.min():.0f}, max {tot.max():.0f}")
+real = buf[:, 15].astype(np.float64) * 0.01   # us: ticks of the constant 100 MHz counter
+print(f"step {ms * 1e3:.1f} us, {len(buf)} waves sampled (every 8th / 16th); life mean {tot.mean():.0f} cycles, min {tot.min():.0f}, max {tot.max():.0f}; "
+      f"in real time {real.mean():.2f} us (the cycle counter runs at {tot.mean() / real.mean() / 1e3:.2f} GHz)")
+if encode or real.mean() * 4 < ms * 1e3:   # (a workgroup per tile; the decode's walk keeps its workgroups for the whole call)
+    ntiles = (W // 128) * (H // (32 if encode else 64))
+    print(f"  {ntiles} workgroups x {real.mean():.2f} us = {ntiles * real.mean() / 1e3:.1f} ms of workgroup life in a step of {ms * 1e3:.1f} us: "
+          f"{ntiles * real.mean() / (ms * 1e3):.0f} workgroups resident on average ({ntiles * real.mean() / (ms * 1e3) / 256:.2f} per CU)")
 for i, n in enumerate(names):
     c = buf[:, i].astype(np.float64)
     print(f"  {n:40s} {c.mean():9.0f} cycles  {100 * c.mean() / tot.mean():5.1f} %   (min {c.min():.0f}, median {np.median(c):.0f}, max {c.max():.0f})")

@@ -7,16 +7,18 @@
 // Output: the reference's Rectangular, uint16 [H][W][count].  No Planar intermediate in HBM: 128 B per coefficient block in,
 // 2 B per sample out ("stops at Rectangular").
 //
-// EXACT BY CONSTRUCTION: this kernel keeps the reference's LITERAL operation sequence -- the same float operations in the
-// same order as kernels_stage.hip's k_idct_plane + k_planar_to_pixels (dct.hpp op for op; per pixel the truncating
-// quotient / remainder of decode.swift:4240-4241, the index clamp to the PADDED plane :4245-4246, t = clamp(Float(f) / Float(c))
-// by a true division :4250-4251, the two-step interpolation :4260-4261 and .rounded() :4264).  None of the enumerated
-// shortcuts of the 8-bit kernels (exact small-integer filters, FMA colour, reciprocal quantiser) is used: those are proofs by
-// exhaustion over 8-bit domains.  The only thing shared between pixels is the table of t values: Float(f) / Float(c) is
-// computed once per (plane, axis, f) -- f = -1 .. c - 1 -- by the same division, instead of once per pixel.
+// EXACT BY CONSTRUCTION: phase A is dct.hpp op for op, as in kernels_stage.hip's k_idct_plane.  Phase B has two forms.  The LITERAL
+// one -- per pixel the truncating quotient / remainder of decode.swift:4240-4241, the index clamp to the PADDED plane :4245-4246,
+// t = clamp(Float(f) / Float(c)) by a true division :4250-4251 (once per (plane, axis, f), not once per pixel), the two-step
+// interpolation :4260-4261 and .rounded() :4264 -- serves the pixels at a plane's edge and the planes whose weights are thirds.
+// Everywhere else (round 6) the weights are binary fractions and the samples integers below 2^16: every product and sum of the
+// reference's expression is exactly representable, so its value is evaluated in fewer operations on the same exact numbers (see
+// the comment in phase B).  None of the ENUMERATED shortcuts of the 8-bit kernels (FMA colour, proofs by exhaustion over 8-bit
+// domains) is used here; the quantiser of the encode below is proven for every 16-bit table (tools/verify_div16.hip).
 //
-// Work decomposition.  One workgroup = one tile of 128 x TH pixels (TH = 64 when the tile's blocks fit 256 work-items, else
-// 32).  Phase A: one 8 x 8 block per work-item (dct.hpp: both passes and transposes are register renames) over the blocks
+// Work decomposition.  The unit is one tile of 128 x TH pixels (TH = 64 when the tile's blocks fit 256 work-items, else 32): a
+// workgroup per tile, or -- WALK, for the layouts it pays for (launch_generic_fused) -- resident workgroups that draw their tiles
+// from a counter.  Phase A: one 8 x 8 block per work-item (dct.hpp: both passes and transposes are register renames) over the blocks
 // of every plane that the tile's pixels read -- for a plane at half resolution that includes a ring of one block, the
 // bilinear filter reaches one sample beyond the tile (decode.swift:4243-4257) -- clamp + truncate (decode.swift:4121-4122),
 // samples into an LDS tile as uint16.  Phase B: a work-item takes 16 consecutive pixels of a row, gathers every plane's

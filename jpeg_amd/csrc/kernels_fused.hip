@@ -61,6 +61,7 @@ struct LumaArgs {
     size_t out_stride;
     int tiles_x, tiles_per_image;
     int first_tile, total_tiles;   // this launch walks strips [first_tile, total_tiles) of the call
+    int pair;                      // 4:4:0: a unit of the walk is a PAIR of strip rows (calls with more strips than resident waves)
 };
 
 // SX, SY: chroma subsampling per axis (1 or 2); MODE: 0 = YCbCr bytes, 1 = RGB bytes;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     auto dma_unit_head = [&](int unit, int lane) {   // what a unit needs first: its (first strip's) chroma blocks, or its luma blocks
         int img, uyi, sxi;
         locate(unit, img, uyi, sxi);
-        dma_at(img, PAIR ? 2 * uyi : uyi, sxi, lane, INSTRIP ? 1 : 0);
+        dma_at(img, (PAIR && a.pair) ? 2 * uyi : uyi, sxi, lane, INSTRIP ? 1 : 0);
     };
     dma_unit_head(s, lane0);
     int img_of_table = -1;
@@ -250,8 +251,9 @@ __global__ __launch_bounds__(kThreads, (luma_waves_per_simd<SX, SY, CHROMA>())) 
     for (; k < len; k += nwaves, s = strip_at(min(k, len - 1))) {
       int img, uyi, sxi;
       locate(s, img, uyi, sxi);
-      const int syi0 = PAIR ? 2 * uyi : uyi;
-      const int nph = (PAIR && syi0 + 1 < strips_y) ? 2 : 1;   // strips of this unit
+      const bool paired = PAIR && a.pair;   // (wave-uniform; small calls walk single strips: a pair is two strips in a row on ONE wave)
+      const int syi0 = paired ? 2 * uyi : uyi;
+      const int nph = (paired && syi0 + 1 < strips_y) ? 2 : 1;   // strips of this unit
 #pragma unroll 1
       for (int ph = 0; ph < nph; ++ph) {
         // Launder the lane id once per strip: everything below that depends only on the lane is
@@ -781,7 +783,11 @@ hipError_t launch_fused_decode(hipStream_t stream, int n_images, const jpeg_amd_
     const int bx = strip_width(la.ux, la.uy, sx, sy), by = 64 / bx;
     la.tiles_x = (la.ux + bx - 1) / bx;
     const int strips_y = (la.uy + by - 1) / by;
-    const bool pairs = chroma && sx == 1 && sy == 2;           // 4:4:0: a unit of the walk is a pair of strip rows (k_luma_fused, PAIR)
+    // 4:4:0: a unit of the walk is a pair of strip rows (k_luma_fused, PAIR) -- when the call has more strips than waves are resident
+    // (two workgroups of four per CU): a pair is two strips in a row on one wave, and a small call has waves to spare
+    // (1920 x 1080: 10.8 us with single strips, 17.3 with pairs; 4096 x 4096: 30.9 against 26.7)
+    const bool pairs = chroma && sx == 1 && sy == 2 && (long)la.tiles_x * strips_y * n_images > 4L * resident_workgroups<1, 2, 1, true, true, 16>();   // (four waves per workgroup)
+    la.pair = pairs ? 1 : 0;
     la.tiles_per_image = la.tiles_x * (pairs ? (strips_y + 1) / 2 : strips_y);
     la.first_tile = 0;
     la.total_tiles = la.tiles_per_image * n_images;

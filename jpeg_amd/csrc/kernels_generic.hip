@@ -844,7 +844,9 @@ hipError_t launch_generic_fused(hipStream_t stream, int n_images, const jpeg_amd
     }
 #define JA_G(TH_, C_)                                                                                                   \
     {                                                                                                                   \
-        if (TH_ == 64 && walk) JA_GK((k_generic_fused<64, C_, true>))                                                   \
+        /* (a call of at most one round keeps the straight-line kernel: nothing to walk) */                             \
+        if (TH_ == 64 && walk && a.total_tiles > resident_workgroups_of<k_generic_fused<64, C_, true>>(3))              \
+            JA_GK((k_generic_fused<64, C_, true>))                                                                      \
         else hipLaunchKernelGGL((k_generic_fused<TH_, C_, false>), dim3(a.tiles_per_image, n_images), dim3(kGThreads), 0, stream, a); \
     }
 #define JA_GC(TH_)                               \

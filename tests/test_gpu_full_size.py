@@ -294,3 +294,32 @@ def test_single_image_and_batch_of_420_agree(env):
         assert e["torch"].equal(single, batch[i]), f"image {i}: the two 4:2:0 paths differ"
     want = _oracle_rgb(e, [p[1].cpu().numpy() for p in planes], size)
     assert (batch[1].cpu().numpy().reshape(-1, 3) == want).all()
+
+
+def test_440_batch_in_pairs_of_strips_equals_single_images_in_single_strips(env):
+    """4:4:0 (k_luma_fused): a batch with more strips than waves are resident walks PAIRS of strip rows that share a chroma tile, a small
+    call single strips (LumaArgs::pair, decided per call).  40 images of 600 x 437 -- 5 x 14 strips each, an odd number of strip rows, so
+    every image ends in a half pair -- decoded in one call (2 800 strips: pairs) and one by one (70: single): identical, and equal
+    to the oracle."""
+    e = env
+    torch, _lib, J = e["torch"], e["_lib"], e["J"]
+    layout = J.Layout("ycc8", {1: J.Component((1, 2), 0), 2: J.Component((1, 1), 1), 3: J.Component((1, 1), 1)})
+    size, n = (600, 437), 40
+    units = layout.units(size)
+    L = layout.c_layout(size, units, [0, 1, 1])
+    planes = e["synth"].natural_planes_torch(units, n, e["ctx"].torch_device, 44)
+    npx = size[0] * size[1] * 3
+
+    def decode(ps, k):
+        out = torch.empty((k, npx), dtype=torch.uint8, device=e["ctx"].torch_device)
+        st = e["lib"].jpeg_amd_decode_batch(e["ctx"].handle, C.byref(L), k, _lib.ptr_array([p.data_ptr() for p in ps]),
+                                           _lib.size_array([64 * a * b for a, b in units]), e["d_q"].data_ptr(), 0, 2, 0,
+                                           _lib.COLOR_RGB8, out.data_ptr(), npx)
+        assert st == 0
+        return out
+
+    batch = decode(planes, n)
+    for i in range(n):
+        assert torch.equal(decode([p[i:i + 1] for p in planes], 1)[0], batch[i]), i
+    _, rect = O.decode([p[7].cpu().numpy() for p in planes], [e["q"][0], e["q"][1], e["q"][1]], [(1, 2), (1, 1), (1, 1)], size, threads=THREADS)
+    assert (batch[7].cpu().numpy().reshape(-1, 3) == O.unpack_rgb8(rect, 3, threads=THREADS)).all()
